@@ -1,0 +1,216 @@
+// host side of the GEMM / implicit-GEMM core: argument checking, tile selection, split-K.
+#include <mutex>
+#include <unordered_set>
+#include <stdarg.h>
+#include "gemm_launch.h"
+
+namespace hs {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+bool lds_attr_needed(const void* fn) {
+    static std::mutex mu;
+    static std::unordered_set<const void*> seen;
+    std::lock_guard<std::mutex> lk(mu);
+    return seen.insert(fn).second;
+}
+
+static int combo_of(int ak, int bk) {
+    if (ak == HS_A_KC && bk == HS_B_KC) return 0;
+    if (ak == HS_A_KC && bk == HS_B_RC) return 1;
+    if (ak == HS_A_RC && bk == HS_B_RC) return 2;
+    if (ak == HS_A_CONV && bk == HS_B_KC) return 3;
+    if (ak == HS_A_DGRAD && bk == HS_B_WDGRAD) return 4;
+    if (ak == HS_A_RC && bk == HS_B_CONV) return 5;
+    return -1;
+}
+
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
+    HS_REQUIRE(p != nullptr, "hs_gemm: null params");
+    HS_REQUIRE(p->dtype == HS_F32 || p->dtype == HS_BF16, "hs_gemm: bad dtype %d", p->dtype);
+    HS_REQUIRE(p->M > 0 && p->N > 0 && p->K >= 0, "hs_gemm: bad dims %d %d %d", p->M, p->N, p->K);
+    HS_REQUIRE(p->A && p->B && p->D, "hs_gemm: null operand");
+    const int combo = combo_of(p->a_kind, p->b_kind);
+    HS_REQUIRE(combo >= 0, "hs_gemm: unsupported operand kinds (%d,%d)", p->a_kind, p->b_kind);
+    const bool bf16 = p->dtype == HS_BF16;
+    const int esz = bf16 ? 2 : 4, epc = bf16 ? 8 : 4;
+    const int batch = p->batch > 0 ? p->batch : 1;
+    const int split = p->split_k > 1 ? p->split_k : 1;
+    HS_REQUIRE(!(batch > 1 && split > 1), "hs_gemm: batch and split_k are exclusive");
+    HS_REQUIRE((long long)p->a_elems * esz < 0x7fffff00ll && (long long)p->b_elems * esz < 0x7fffff00ll,
+               "hs_gemm: operand larger than 2 GiB");
+    HS_REQUIRE(p->out_dtype == HS_F32 || p->out_dtype == p->dtype, "hs_gemm: out_dtype must be f32 or the operand type");
+    HS_REQUIRE(!p->accumulate || p->out_dtype == HS_F32, "hs_gemm: accumulate needs an f32 output");
+
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = (const char*)p->A;
+    a.B = (const char*)p->B;
+    a.a_bytes = (unsigned long long)p->a_elems * esz;
+    a.b_bytes = (unsigned long long)p->b_elems * esz;
+    a.lda = p->lda;
+    a.ldb = p->ldb;
+    a.M = p->M;
+    a.N = p->N;
+    a.K = p->K;
+    a.g = p->g;
+    a.batch_inner = p->batch_inner > 0 ? p->batch_inner : 1;
+    a.a_bs0 = p->a_bs0; a.a_bs1 = p->a_bs1;
+    a.b_bs0 = p->b_bs0; a.b_bs1 = p->b_bs1;
+    a.d_bs0 = p->d_bs0; a.d_bs1 = p->d_bs1;
+    a.D = (char*)p->D;
+    a.ldd = p->ldd;
+    a.out_f32 = p->out_dtype == HS_F32;
+    a.alpha = p->alpha;
+    a.bias = p->bias;
+    a.act = p->act;
+    a.D_preact = (char*)p->D_preact;
+    a.residual = (const char*)p->residual;
+    a.ldr = p->ldr;
+    if (p->dropout_p > 0.f) {
+        HS_REQUIRE(p->dropout_p < 1.f, "hs_gemm: dropout_p must be < 1");
+        a.drop_thresh = dropout_thresh(p->dropout_p);
+        a.drop_inv_keep = 1.f / (1.f - p->dropout_p);
+        a.drop_seed = p->dropout_seed;
+    }
+    a.mul_mode = p->mul_mode;
+    a.mul_src = (const char*)p->mul_src;
+    a.ldm = p->ldm;
+    a.accumulate = p->accumulate;
+    HS_REQUIRE(a.mul_mode == HS_MUL_NONE || a.mul_src, "hs_gemm: mul_mode without mul_src");
+
+    // conv geometry
+    const bool conv = combo >= 3;
+    const int bk = bf16 ? 64 : 32;
+    int cfg = -1;
+    if (conv) {
+        const hs_conv_geom& g = p->g;
+        HS_REQUIRE(g.stride == 1 || g.stride == 2, "hs_gemm: conv stride must be 1 or 2");
+        if (combo == 3) {
+            HS_REQUIRE(p->K == g.R * g.S * g.C, "conv fwd: K != R*S*C");
+            HS_REQUIRE(p->M == g.N * g.P * g.Q, "conv fwd: M != N*P*Q");
+            a.div_mhw = make_fastdiv(g.P * g.Q);
+            a.div_mw = make_fastdiv(g.Q);
+            if (bf16 && g.C % 64 != 0) {
+                HS_REQUIRE(g.C % 32 == 0 && p->N <= 64, "conv fwd (bf16): C must be a multiple of 64 (or 32 with N<=64)");
+                cfg = CFG_STEM;
+            } else {
+                HS_REQUIRE(g.C % bk == 0, "conv fwd: C %% %d != 0", bk);
+            }
+        } else if (combo == 4) {
+            HS_REQUIRE(p->K == g.R * g.S * g.K, "conv dgrad: K != R*S*Kout");
+            HS_REQUIRE(p->M == g.N * g.H * g.W, "conv dgrad: M != N*H*W");
+            HS_REQUIRE(p->N == g.C, "conv dgrad: N != C");
+            HS_REQUIRE(g.K % bk == 0, "conv dgrad: Kout %% %d != 0", bk);
+            a.div_mhw = make_fastdiv(g.H * g.W);
+            a.div_mw = make_fastdiv(g.W);
+        } else {
+            HS_REQUIRE(p->K == g.N * g.P * g.Q, "conv wgrad: K != N*P*Q");
+            HS_REQUIRE(p->N == g.R * g.S * g.C, "conv wgrad: N != R*S*C");
+            HS_REQUIRE(p->M == g.K, "conv wgrad: M != Kout");
+            HS_REQUIRE(g.C % epc == 0, "conv wgrad: C %% %d != 0", epc);
+            a.div_mhw = make_fastdiv(g.P * g.Q);
+            a.div_mw = make_fastdiv(g.Q);
+            a.div_sc = make_fastdiv(g.S * g.C);
+            a.div_c = make_fastdiv(g.C);
+        }
+    }
+
+    // vector-path eligibility (16-byte chunks): strides and bases chunk aligned.
+    bool vec = aligned16(p->A) && aligned16(p->B);
+    if (p->a_kind == HS_A_KC || p->a_kind == HS_A_RC) vec = vec && (p->lda % epc == 0);
+    if (p->b_kind == HS_B_KC || p->b_kind == HS_B_RC) vec = vec && (p->ldb % epc == 0);
+    if (batch > 1) vec = vec && (p->a_bs0 % epc == 0) && (p->a_bs1 % epc == 0) && (p->b_bs0 % epc == 0) && (p->b_bs1 % epc == 0);
+    if (conv) HS_REQUIRE(vec, "hs_gemm: conv operands must be 16-byte aligned");
+    if (bf16) HS_REQUIRE(vec, "hs_gemm(bf16): lda/ldb/batch strides must be multiples of 8 and bases 16-byte aligned");
+    // 4-wide epilogue accesses
+    {
+        const int oesz = a.out_f32 ? 4 : esz;
+        bool vs = (p->N % 4 == 0) && (p->ldd % 4 == 0) && ((((uintptr_t)p->D) % (4 * oesz)) == 0);
+        if (batch > 1) vs = vs && (p->d_bs0 % 4 == 0) && (p->d_bs1 % 4 == 0);
+        if (p->D_preact) vs = vs && ((((uintptr_t)p->D_preact) % (4 * oesz)) == 0);
+        if (p->residual) vs = vs && (p->ldr % 4 == 0) && ((((uintptr_t)p->residual) % (4 * oesz)) == 0);
+        if (p->mul_src) vs = vs && (p->ldm % 4 == 0) && ((((uintptr_t)p->mul_src) % (4 * esz)) == 0);
+        a.vec_store = vs;
+    }
+
+    // tile selection: biggest tile that still gives the chip >= ~1 block per CU
+    if (cfg < 0) {
+        const long long z = (long long)batch * split;
+        const long long t128 = (long long)ceil_div(p->M, 128) * ceil_div(p->N, 128) * z;
+        const long long t12864 = (long long)ceil_div(p->M, 128) * ceil_div(p->N, 64) * z;
+        if (bf16) {
+            if (p->N > 64 && t128 >= 200) cfg = CFG_128x128;
+            else if (t12864 >= 200) cfg = CFG_128x64;
+            else cfg = CFG_64x64;
+        } else {
+            cfg = (vec && t128 >= 200) ? CFG_128x128 : CFG_64x64;
+        }
+    }
+    int BM = 64, BN = 64;
+    if (cfg == CFG_128x128) { BM = 128; BN = 128; }
+    else if (cfg == CFG_128x64 || cfg == CFG_STEM) { BM = 128; BN = 64; }
+    a.tiles_m = ceil_div(p->M, BM);
+    a.tiles_n = ceil_div(p->N, BN);
+
+    a.split_k = split;
+    if (split > 1) {
+        HS_REQUIRE(p->splitk_ws != nullptr, "hs_gemm: split_k needs a workspace");
+        const int kb = (cfg == CFG_STEM) ? 32 : bk;
+        const int ktiles = ceil_div(p->K, kb);
+        a.k_per_split = ceil_div(ktiles, split) * kb;
+        a.splitk_ws = p->splitk_ws;
+    }
+    dim3 grid(a.tiles_m * a.tiles_n, 1, split > 1 ? split : batch);
+    int st;
+    if (bf16) st = conv ? launch_bf16_conv(cfg, combo, a, grid, stream) : launch_bf16_plain(cfg, combo, a, grid, stream);
+    else st = conv ? launch_f32_conv(cfg, combo, a, grid, stream) : launch_f32_plain(cfg, combo, vec, a, grid, stream);
+    HS_PROPAGATE(st);
+    if (split > 1) {
+        const long long work = (long long)p->M * ((p->N + 3) / 4);
+        const int blocks = (int)std::min<long long>((work + 255) / 256, 2048);
+        if (bf16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, a);
+        HS_LAUNCH_CHECK();
+    }
+    return HS_OK;
+}
+
+}  // namespace hs
+
+extern "C" {
+const char* hs_last_error(void) { return hs::last_error(); }
+int hs_version(void) { return 100; }
+int hs_device_ok(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+hs_status hs_gemm(const hs_gemm_params* p, void* stream) { return hs::gemm_impl(p, (hipStream_t)stream); }
+int64_t hs_gemm_splitk_ws_bytes(const hs_gemm_params* p) {
+    if (!p || p->split_k <= 1) return 0;
+    return (int64_t)p->split_k * p->M * p->N * 4;
+}
+int32_t hs_gemm_suggest_split(int32_t M, int32_t N, int32_t K, int32_t dtype) {
+    const int bk = dtype == HS_BF16 ? 64 : 32;
+    const long long tiles = (long long)hs::ceil_div(M, 64) * hs::ceil_div(N, 64);
+    const int ktiles = hs::ceil_div(K, bk);
+    if (tiles >= 256 || ktiles < 16) return 1;
+    long long s = (512 + tiles - 1) / tiles;
+    const long long smax = ktiles / 8 > 0 ? ktiles / 8 : 1;   // keep >= 8 k-tiles per split
+    if (s > smax) s = smax;
+    if (s > 64) s = 64;
+    return (int32_t)(s < 1 ? 1 : s);
+}
+}

@@ -1,0 +1,22 @@
+#include "gemm_launch.h"
+namespace hs {
+#define L(BM, BN, BK, AK, BKD) \
+    return launch_with_lds(gemm_bf16_kernel<BM, BN, BK, AK, BKD, true>, 2 * (BM + BN) * BK * 2, a, grid, s)
+#define CFGS(AK, BKD)                              \
+    switch (cfg) {                                 \
+        case CFG_128x128: L(128, 128, 64, AK, BKD); \
+        case CFG_128x64: L(128, 64, 64, AK, BKD);  \
+        case CFG_64x64: L(64, 64, 64, AK, BKD);    \
+    }                                              \
+    break;
+int launch_bf16_conv(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s) {
+    if (cfg == CFG_STEM && combo == 3) L(128, 64, 32, HS_A_CONV, HS_B_KC);
+    switch (combo) {
+        case 3: CFGS(HS_A_CONV, HS_B_KC)
+        case 4: CFGS(HS_A_DGRAD, HS_B_WDGRAD)
+        case 5: CFGS(HS_A_RC, HS_B_CONV)
+    }
+    set_error("launch_bf16_conv: bad cfg/combo %d/%d", cfg, combo);
+    return HS_ERR_ARG;
+}
+}  // namespace hs

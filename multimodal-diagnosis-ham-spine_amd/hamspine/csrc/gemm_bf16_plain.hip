@@ -1,0 +1,21 @@
+#include "gemm_launch.h"
+namespace hs {
+#define L(BM, BN, BK, AK, BKD) \
+    return launch_with_lds(gemm_bf16_kernel<BM, BN, BK, AK, BKD, true>, 2 * (BM + BN) * BK * 2, a, grid, s)
+#define CFGS(AK, BKD)                              \
+    switch (cfg) {                                 \
+        case CFG_128x128: L(128, 128, 64, AK, BKD); \
+        case CFG_128x64: L(128, 64, 64, AK, BKD);  \
+        case CFG_64x64: L(64, 64, 64, AK, BKD);    \
+    }                                              \
+    break;
+int launch_bf16_plain(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s) {
+    switch (combo) {
+        case 0: CFGS(HS_A_KC, HS_B_KC)
+        case 1: CFGS(HS_A_KC, HS_B_RC)
+        case 2: CFGS(HS_A_RC, HS_B_RC)
+    }
+    set_error("launch_bf16_plain: bad cfg/combo %d/%d", cfg, combo);
+    return HS_ERR_ARG;
+}
+}  // namespace hs

@@ -1,0 +1,776 @@
+// MFMA GEMM / implicit-GEMM convolution core for gfx950.
+//
+//   D[m][n] = epilogue( alpha * sum_k A(m,k) * B(n,k) )
+//
+// One 256-thread workgroup (4 waves, 2x2) owns a BM x BN output tile.  Operand tiles are staged
+// global -> registers -> LDS (double buffered; loads for tile t+1 are issued before the MFMAs of
+// tile t and written to LDS after them), so im2col gathers, conv padding and tile tails are all
+// predicated in the loader (out-of-range buffer offsets read as zero).
+//
+// Two MFMA paths share the loaders and the epilogue:
+//   bf16 : v_mfma_f32_16x16x32_bf16, K-contiguous operands sit in LDS as [row][k] (XOR swizzled,
+//          ds_read_b128), row-contiguous ("transposed") operands sit as [k][row] and are read with
+//          ds_read_b64_tr_b16, so wgrad/dgrad need no transposed copies in HBM.
+//   f32  : v_mfma_f32_32x32x2_f32 (bit-exact fmaf chain), both operands sit in LDS as [k][row].
+//
+// MFMA operand roles are swapped (MFMA-A := B tile, MFMA-B := A tile) so that each lane ends up with
+// 4 consecutive n for one m: the epilogue then issues 8/16-byte row-contiguous accesses.
+#pragma once
+#include "hs_common.h"
+
+namespace hs {
+
+struct GemmArgs {
+    const char* A;
+    const char* B;
+    unsigned long long a_bytes, b_bytes;
+    int lda, ldb;
+    int M, N, K;
+    hs_conv_geom g;
+    FastDiv div_mhw, div_mw;   // rows m -> (n, y, x): divide by (Y*X), X
+    FastDiv div_sc, div_c;     // cols   -> (r, s, c): divide by (S*C), C
+    int batch_inner;
+    long long a_bs0, a_bs1, b_bs0, b_bs1, d_bs0, d_bs1;   // in elements
+    int tiles_m, tiles_n;
+    int split_k;               // >1: blockIdx.z is the split index
+    int k_per_split;           // multiple of BK
+    float* splitk_ws;
+    // epilogue
+    char* D;
+    int ldd;
+    int out_f32;
+    float alpha;
+    const float* bias;
+    int act;
+    char* D_preact;
+    const char* residual;
+    int ldr;
+    unsigned drop_thresh;
+    float drop_inv_keep;
+    unsigned long long drop_seed;
+    int mul_mode;
+    const char* mul_src;
+    int ldm;
+    int accumulate;
+    int vec_store;             // 1: N%4==0 and all row strides/bases allow 4-wide accesses
+};
+
+// ------------------------------------------------------------------------------------------------
+// epilogue for 4 consecutive n of one row m.  TIn = element type of mul_src; TOut chosen at run time.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void load4(const char* base, long long idx, bool vec, int nvalid, float* f) {
+    const T* p = (const T*)base + idx;
+    if (vec) {
+        if constexpr (sizeof(T) == 4) {
+            f32x4 v = *(const f32x4*)p;
+            f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+        } else {
+            u32x2 v = *(const u32x2*)p;
+            f[0] = __uint_as_float(v[0] << 16);
+            f[1] = __uint_as_float(v[0] & 0xffff0000u);
+            f[2] = __uint_as_float(v[1] << 16);
+            f[3] = __uint_as_float(v[1] & 0xffff0000u);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = j < nvalid ? to_f32(p[j]) : 0.f;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store4(char* base, long long idx, bool vec, int nvalid, const float* f) {
+    T* p = (T*)base + idx;
+    if (vec) {
+        if constexpr (sizeof(T) == 4) {
+            f32x4 v = {f[0], f[1], f[2], f[3]};
+            *(f32x4*)p = v;
+        } else {
+            bf16x4 v = {(bf16_t)f[0], (bf16_t)f[1], (bf16_t)f[2], (bf16_t)f[3]};
+            *(bf16x4*)p = v;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < nvalid) p[j] = from_f32<T>(f[j]);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue4(const GemmArgs& a, long long dbase, int z, int m, int n, float* v) {
+    if (m >= a.M || n >= a.N) return;
+    const int nvalid = min(4, a.N - n);
+    const bool vec = a.vec_store && nvalid == 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] *= a.alpha;
+    if (a.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < nvalid) v[j] += a.bias[n + j];
+    }
+    if (a.mul_mode != HS_MUL_NONE) {
+        float u[4];
+        load4<T>(a.mul_src, (long long)m * a.ldm + n, vec, nvalid, u);   // mul_src is never batched
+        if (a.mul_mode == HS_MUL_GELU_GRAD) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(u[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = u[j] > 0.f ? v[j] : 0.f;
+        }
+    }
+    const long long didx = dbase + (long long)m * a.ldd + n;
+    if (a.D_preact) {
+        if (a.out_f32) store4<float>(a.D_preact, didx, vec, nvalid, v);
+        else store4<T>(a.D_preact, didx, vec, nvalid, v);
+    }
+    if (a.act == HS_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+    } else if (a.act == HS_ACT_GELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+    }
+    if (a.drop_thresh) {
+        const unsigned long long e = ((unsigned long long)z * a.M + m) * (unsigned long long)a.N + n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= dropout_scale(a.drop_seed, e + j, a.drop_thresh, a.drop_inv_keep);
+    }
+    if (a.residual) {
+        float r[4];
+        const long long ridx = dbase + (long long)m * a.ldr + n;   // residual shares D's batch strides
+        if (a.out_f32) load4<float>(a.residual, ridx, vec, nvalid, r);
+        else load4<T>(a.residual, ridx, vec, nvalid, r);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += r[j];
+    }
+    if (a.out_f32) {
+        if (a.accumulate) {
+            float o[4];
+            load4<float>(a.D, didx, vec, nvalid, o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += o[j];
+        }
+        store4<float>(a.D, didx, vec, nvalid, v);
+    } else {
+        store4<T>(a.D, didx, vec, nvalid, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS layouts
+// ------------------------------------------------------------------------------------------------
+// bf16, K-contiguous tile [rows][BK]: 16-byte chunk `kc` of row `r`.
+template <int BK>
+__device__ __forceinline__ int kc_off_bf16(int r, int kc) {
+    constexpr int CPR = BK / 8;            // chunks per row
+    constexpr int RPB = 16 / CPR;          // rows per 256-byte bank row
+    const int swz = (r / RPB) % CPR;
+    return r * (BK * 2) + ((kc ^ swz) << 4);
+}
+// bf16, row-contiguous tile [BK][BR]: byte offset of element (k, col); 32-byte granules are XOR-ed
+// with a function of k so that the 8 k-rows one half-wave transposed read touches hit distinct banks.
+template <int BR>
+__device__ __forceinline__ int rc_off_bf16(int k, int col) {
+    constexpr int G = BR / 16;             // 32-byte granules per k-row
+    int f;
+    if constexpr (G >= 8) f = (k & 3) | (((k >> 3) & 1) << 2);
+    else f = ((k >> 1) & 1) | (((k >> 3) & 1) << 1);
+    return k * (BR * 2) + ((((col >> 4) ^ f) & (G - 1)) << 5) + ((col & 15) << 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// operand address generation.  All offsets are in BYTES into the operand's buffer resource.
+// ------------------------------------------------------------------------------------------------
+// K-contiguous operand (A only): per-thread row state.
+template <int KIND>
+struct KcRow {
+    int base;      // element offset of the row (plain) / of the image window origin (conv)
+    int hb, wb;    // conv: window origin (may be negative); dgrad: h+pad, w+pad
+    bool valid;
+};
+
+template <int KIND>
+__device__ __forceinline__ void kc_row_setup(const GemmArgs& a, int m, KcRow<KIND>& st) {
+    st.valid = m < a.M;
+    st.hb = st.wb = 0;
+    if constexpr (KIND == HS_A_KC) {
+        st.base = m * a.lda;
+    } else if constexpr (KIND == HS_A_CONV) {
+        const unsigned n = fdiv(m, a.div_mhw);
+        const unsigned pq = m - n * a.div_mhw.d;
+        const unsigned p = fdiv(pq, a.div_mw);
+        const unsigned q = pq - p * a.div_mw.d;
+        st.hb = (int)p * a.g.stride - a.g.pad;
+        st.wb = (int)q * a.g.stride - a.g.pad;
+        st.base = (int)n * a.g.img_pitch + st.hb * a.g.row_pitch + (int)q * a.g.qstep - a.g.pad * a.g.C;
+    } else {   // HS_A_DGRAD: m = (n, h, w) over the conv INPUT grid
+        const unsigned n = fdiv(m, a.div_mhw);
+        const unsigned hw = m - n * a.div_mhw.d;
+        const unsigned h = fdiv(hw, a.div_mw);
+        const unsigned w = hw - h * a.div_mw.d;
+        st.hb = (int)h + a.g.pad;
+        st.wb = (int)w + a.g.pad;
+        st.base = (int)n * a.g.P * a.g.Q * a.g.K;
+    }
+}
+
+// uniform (per k-tile) decomposition of k0 -> (r, s, c0) with channel count CH
+struct KTile {
+    int r, s, c0;
+};
+__device__ __forceinline__ KTile ktile_rsc(int k0, int CH, int S) {
+    KTile t;
+    const int rs = k0 / CH;
+    t.c0 = k0 - rs * CH;
+    t.r = rs / S;
+    t.s = rs - t.r * S;
+    return t;
+}
+
+template <int KIND, int ESZ>
+__device__ __forceinline__ unsigned kc_chunk_off(const GemmArgs& a, const KcRow<KIND>& st, const KTile& kt,
+                                                 int k, int kend) {
+    // k = absolute k index of the chunk's first element
+    bool ok = st.valid && k < kend;
+    int off;
+    if constexpr (KIND == HS_A_KC) {
+        off = st.base + k;
+    } else if constexpr (KIND == HS_A_CONV) {
+        const int h = st.hb + kt.r, w = st.wb + kt.s;
+        if (!a.g.no_bounds) ok = ok && (unsigned)h < (unsigned)a.g.H && (unsigned)w < (unsigned)a.g.W;
+        off = st.base + kt.r * a.g.row_pitch + kt.s * a.g.C + (k - (kt.r * a.g.S + kt.s) * a.g.C);
+    } else {
+        int hp = st.hb - kt.r, wp = st.wb - kt.s;
+        ok = ok && hp >= 0 && wp >= 0;
+        if (a.g.stride == 2) {
+            ok = ok && !((hp | wp) & 1);
+            hp >>= 1;
+            wp >>= 1;
+        }
+        ok = ok && hp < a.g.P && wp < a.g.Q;
+        off = st.base + (hp * a.g.Q + wp) * a.g.K + (k - (kt.r * a.g.S + kt.s) * a.g.K);
+    }
+    return ok ? (unsigned)off * ESZ : kOOB;
+}
+
+// Row-contiguous operands (A_RC, B_RC, B_WDGRAD, B_CONV): chunk = EPC consecutive rows/cols at one k.
+struct RcCol {
+    int base;     // element offset contribution of the column chunk
+    int r, s;     // B_CONV: filter tap of the column chunk
+    bool valid;
+};
+template <int KIND, bool IS_A>
+__device__ __forceinline__ void rc_col_setup(const GemmArgs& a, int col, RcCol& st) {
+    st.r = st.s = 0;
+    if constexpr (IS_A) {
+        st.valid = col < a.M;
+        st.base = col;
+    } else if constexpr (KIND == HS_B_RC) {
+        st.valid = col < a.N;
+        st.base = col;
+    } else if constexpr (KIND == HS_B_WDGRAD) {
+        st.valid = col < a.N;   // n = c (input channel)
+        st.base = col;
+    } else {   // HS_B_CONV: col = (r, s, c)
+        st.valid = col < a.N;
+        const unsigned r = fdiv(col, a.div_sc);
+        const unsigned sc = col - r * a.div_sc.d;
+        const unsigned s = fdiv(sc, a.div_c);
+        const unsigned c = sc - s * a.div_c.d;
+        st.r = r;
+        st.s = s;
+        st.base = (int)r * a.g.row_pitch + ((int)s - a.g.pad) * a.g.C + (int)c;
+    }
+}
+template <int KIND, bool IS_A, int ESZ>
+__device__ __forceinline__ unsigned rc_chunk_off(const GemmArgs& a, const RcCol& st, const KTile& kt, int k,
+                                                 int kend) {
+    bool ok = st.valid && k < kend;
+    int off;
+    if constexpr (IS_A) {
+        off = k * a.lda + st.base;
+    } else if constexpr (KIND == HS_B_RC) {
+        off = k * a.ldb + st.base;
+    } else if constexpr (KIND == HS_B_WDGRAD) {
+        // k = (r, s, ko); filter element [ko][r][s][c]
+        const int rs = kt.r * a.g.S + kt.s;
+        const int ko = k - rs * a.g.K;
+        off = ko * (a.g.R * a.g.S * a.g.C) + rs * a.g.C + st.base;
+    } else {
+        // k = m = (n, p, q)
+        const unsigned n = fdiv(k, a.div_mhw);
+        const unsigned pq = k - n * a.div_mhw.d;
+        const unsigned p = fdiv(pq, a.div_mw);
+        const unsigned q = pq - p * a.div_mw.d;
+        const int h = (int)p * a.g.stride - a.g.pad + st.r;
+        const int w = (int)q * a.g.stride - a.g.pad + st.s;
+        if (!a.g.no_bounds) ok = ok && (unsigned)h < (unsigned)a.g.H && (unsigned)w < (unsigned)a.g.W;
+        off = (int)n * a.g.img_pitch + ((int)p * a.g.stride - a.g.pad) * a.g.row_pitch + (int)q * a.g.qstep + st.base;
+    }
+    return ok ? (unsigned)off * ESZ : kOOB;
+}
+
+// scalar-element fallback load of one chunk (used when strides/sizes are not chunk aligned):
+// element j of a K-contiguous chunk is valid while k+j < kend; of a row-contiguous chunk while col+j < limit.
+template <typename T>
+__device__ __forceinline__ u32x4 load_chunk(__amdgpu_buffer_rsrc_t rs, unsigned off, bool vec, int nvalid) {
+    if (vec) return buf_load16(rs, off);
+    u32x4 c = {0, 0, 0, 0};
+    if (off == kOOB) return c;
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < nvalid) c[j] = buf_load4(rs, off + 4 * j);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < nvalid) {
+                unsigned v = buf_load2(rs, off + 2 * j);
+                c[j >> 1] |= (j & 1) ? (v << 16) : v;
+            }
+    }
+    return c;
+}
+
+// zero the elements of a K-contiguous chunk that lie at or beyond kend (only taken when K % chunk != 0)
+template <typename T>
+__device__ __forceinline__ void mask_tail(u32x4& c, int nvalid) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j >= nvalid) c[j] = 0u;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j >= nvalid) c[j >> 1] &= (j & 1) ? 0x0000ffffu : 0xffff0000u;
+    }
+}
+
+constexpr bool a_is_rc(int k) { return k == HS_A_RC; }
+constexpr bool b_is_rc(int k) { return k != HS_B_KC; }
+
+__device__ __forceinline__ void tile_from_block(const GemmArgs& a, int& tm, int& tn) {
+    // XCD-aware remap: the 8 XCDs get contiguous runs of tiles (bijective for any grid size), and
+    // inside a run tiles walk n fastest so neighbours share the A panel through the XCD's L2.
+    const int nwg = a.tiles_m * a.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    tm = id / a.tiles_n;
+    tn = id - tm * a.tiles_n;
+}
+
+// ================================================================================================
+// bf16 kernel
+// ================================================================================================
+template <int BM, int BN, int BK, int AK, int BKIND, bool VEC>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
+    typedef bf16_t T;
+    constexpr int EPC = 8, ESZ = 2;
+    constexpr bool A_RC = a_is_rc(AK), B_RC = b_is_rc(BKIND);
+    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_NCH = BM * BK / 8 / 256, B_NCH = BN * BK / 8 / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 4, l15 = lane & 15;
+    int tm, tn;
+    tile_from_block(a, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.z;
+
+    long long a_boff = 0, b_boff = 0, d_boff = 0;
+    int kbeg = 0, kend = a.K;
+    if (a.split_k > 1) {
+        kbeg = z * a.k_per_split;
+        kend = min(a.K, kbeg + a.k_per_split);
+    } else {
+        const int zo = z / a.batch_inner, zi = z - zo * a.batch_inner;
+        a_boff = zo * a.a_bs0 + zi * a.a_bs1;
+        b_boff = zo * a.b_bs0 + zi * a.b_bs1;
+        d_boff = zo * a.d_bs0 + zi * a.d_bs1;
+    }
+    const unsigned long long a_rem = a.a_bytes - (unsigned long long)a_boff * ESZ;
+    const unsigned long long b_rem = a.b_bytes - (unsigned long long)b_boff * ESZ;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.A + a_boff * ESZ, (unsigned)min(a_rem, 0x7fffff00ull));
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.B + b_boff * ESZ, (unsigned)min(b_rem, 0x7fffff00ull));
+
+    // ---- per-thread staging state ------------------------------------------------------------
+    KcRow<A_RC ? HS_A_KC : AK> a_rows[A_RC ? 1 : A_NCH];
+    RcCol a_col;
+    RcCol b_col;
+    KcRow<HS_A_KC> b_rows[B_RC ? 1 : B_NCH];
+    constexpr int CPR = BK / 8;
+    if constexpr (!A_RC) {
+#pragma unroll
+        for (int i = 0; i < A_NCH; ++i) kc_row_setup<AK>(a, m0 + (tid + 256 * i) / CPR, a_rows[i]);
+    } else {
+        rc_col_setup<AK, true>(a, m0 + (tid % (BM / 8)) * 8, a_col);
+    }
+    if constexpr (!B_RC) {
+#pragma unroll
+        for (int i = 0; i < B_NCH; ++i) {
+            const int n = n0 + (tid + 256 * i) / CPR;
+            b_rows[i].valid = n < a.N;
+            b_rows[i].base = n * a.ldb;
+            b_rows[i].hb = b_rows[i].wb = 0;
+        }
+    } else {
+        rc_col_setup<BKIND, false>(a, n0 + (tid % (BN / 8)) * 8, b_col);
+    }
+
+    u32x4 a_reg[A_NCH], b_reg[B_NCH];
+
+    auto stage_load = [&](int k0) {
+        // uniform tap decomposition for conv kinds (BK divides the channel count)
+        KTile kta = {0, 0, 0}, ktb = {0, 0, 0};
+        if constexpr (AK == HS_A_CONV) kta = ktile_rsc(k0, a.g.C, a.g.S);
+        if constexpr (AK == HS_A_DGRAD) kta = ktile_rsc(k0, a.g.K, a.g.S);
+        if constexpr (BKIND == HS_B_WDGRAD) ktb = ktile_rsc(k0, a.g.K, a.g.S);
+#pragma unroll
+        for (int i = 0; i < A_NCH; ++i) {
+            const int id = tid + 256 * i;
+            unsigned off;
+            int nvalid = 8;
+            if constexpr (!A_RC) {
+                const int k = k0 + (id % CPR) * 8;
+                off = kc_chunk_off<AK, ESZ>(a, a_rows[i], kta, k, kend);
+                nvalid = kend - k;
+            } else {
+                const int k = k0 + id / (BM / 8);
+                off = rc_chunk_off<AK, true, ESZ>(a, a_col, kta, k, kend);
+                if constexpr (!VEC) nvalid = a.M - a_col.base;
+            }
+            a_reg[i] = load_chunk<T>(rsA, off, VEC, nvalid);
+            if constexpr (!A_RC && VEC) if (nvalid < 8 && nvalid > 0) mask_tail<T>(a_reg[i], nvalid);
+        }
+#pragma unroll
+        for (int i = 0; i < B_NCH; ++i) {
+            const int id = tid + 256 * i;
+            unsigned off;
+            int nvalid = 8;
+            if constexpr (!B_RC) {
+                const int k = k0 + (id % CPR) * 8;
+                off = kc_chunk_off<HS_A_KC, ESZ>(a, b_rows[i], ktb, k, kend);
+                nvalid = kend - k;
+            } else {
+                const int k = k0 + id / (BN / 8);
+                off = rc_chunk_off<BKIND, false, ESZ>(a, b_col, ktb, k, kend);
+                if constexpr (!VEC) nvalid = a.N - (n0 + (tid % (BN / 8)) * 8);
+            }
+            b_reg[i] = load_chunk<T>(rsB, off, VEC, nvalid);
+            if constexpr (!B_RC && VEC) if (nvalid < 8 && nvalid > 0) mask_tail<T>(b_reg[i], nvalid);
+        }
+    };
+    auto stage_write = [&](int buf) {
+        char* sa = smem + buf * STAGE;
+        char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_NCH; ++i) {
+            const int id = tid + 256 * i;
+            int off;
+            if constexpr (!A_RC) off = kc_off_bf16<BK>(id / CPR, id % CPR);
+            else off = rc_off_bf16<BM>(id / (BM / 8), (id % (BM / 8)) * 8);
+            *(u32x4*)(sa + off) = a_reg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_NCH; ++i) {
+            const int id = tid + 256 * i;
+            int off;
+            if constexpr (!B_RC) off = kc_off_bf16<BK>(id / CPR, id % CPR);
+            else off = rc_off_bf16<BN>(id / (BN / 8), (id % (BN / 8)) * 8);
+            *(u32x4*)(sb + off) = b_reg[i];
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = (kend - kbeg + BK - 1) / BK;
+    if (ntiles > 0) {
+        stage_load(kbeg);
+        stage_write(0);
+    }
+    __syncthreads();
+
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) stage_load(kbeg + (t + 1) * BK);
+        const char* sa = smem + cur * STAGE;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 af[FM], bfr[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int r0 = wm * WM + i * 16;
+                if constexpr (!A_RC) {
+                    af[i] = *(const bf16x8*)(sa + kc_off_bf16<BK>(r0 + l15, ks * 4 + g));
+                } else {
+                    const int kb = ks * 32 + 8 * g + (l15 >> 2);
+                    const int col = r0 + 4 * (lane & 3);
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4 __attribute__((address_space(3)))*)(sa + rc_off_bf16<BM>(kb, col)));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4 __attribute__((address_space(3)))*)(sa + rc_off_bf16<BM>(kb + 4, col)));
+                    af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int r0 = wn * WN + j * 16;
+                if constexpr (!B_RC) {
+                    bfr[j] = *(const bf16x8*)(sb + kc_off_bf16<BK>(r0 + l15, ks * 4 + g));
+                } else {
+                    const int kb = ks * 32 + 8 * g + (l15 >> 2);
+                    const int col = r0 + 4 * (lane & 3);
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4 __attribute__((address_space(3)))*)(sb + rc_off_bf16<BN>(kb, col)));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4 __attribute__((address_space(3)))*)(sb + rc_off_bf16<BN>(kb + 4, col)));
+                    bfr[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < ntiles) stage_write(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns m = .. + l15, n = .. + 4g + {0..3} ---------------------------------
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * WM + i * 16 + l15;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * WN + j * 16 + 4 * g;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (a.split_k > 1) {
+                if (m < a.M && n < a.N) {
+                    float* w = a.splitk_ws + ((long long)z * a.M + m) * a.N + n;
+                    if (n + 3 < a.N && (a.N & 3) == 0) *(f32x4*)w = f32x4{v[0], v[1], v[2], v[3]};
+                    else
+                        for (int e = 0; e < 4 && n + e < a.N; ++e) w[e] = v[e];
+                }
+            } else {
+                epilogue4<T>(a, d_boff, z, m, n, v);
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// exact-f32 kernel (v_mfma_f32_32x32x2_f32); BK = 32
+// ================================================================================================
+template <int BM, int BN, int AK, int BKIND, bool VEC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs a) {
+    typedef float T;
+    constexpr int BK = 32, EPC = 4, ESZ = 4;
+    constexpr bool A_RC = a_is_rc(AK), B_RC = b_is_rc(BKIND);
+    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 32, FN = WN / 32;
+    constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_NCH = BM * BK / 4 / 256, B_NCH = BN * BK / 4 / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+    int tm, tn;
+    tile_from_block(a, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.z;
+
+    long long a_boff = 0, b_boff = 0, d_boff = 0;
+    int kbeg = 0, kend = a.K;
+    if (a.split_k > 1) {
+        kbeg = z * a.k_per_split;
+        kend = min(a.K, kbeg + a.k_per_split);
+    } else {
+        const int zo = z / a.batch_inner, zi = z - zo * a.batch_inner;
+        a_boff = zo * a.a_bs0 + zi * a.a_bs1;
+        b_boff = zo * a.b_bs0 + zi * a.b_bs1;
+        d_boff = zo * a.d_bs0 + zi * a.d_bs1;
+    }
+    const unsigned long long a_rem = a.a_bytes - (unsigned long long)a_boff * ESZ;
+    const unsigned long long b_rem = a.b_bytes - (unsigned long long)b_boff * ESZ;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.A + a_boff * ESZ, (unsigned)min(a_rem, 0x7fffff00ull));
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.B + b_boff * ESZ, (unsigned)min(b_rem, 0x7fffff00ull));
+
+    // K-contiguous staging: chunk id -> row = id % ROWS (lane-fastest: conflict-free LDS scatter),
+    // kc = id / ROWS.  Row-contiguous staging: id -> k = id / (ROWS/4), cc = id % (ROWS/4).
+    KcRow<A_RC ? HS_A_KC : AK> a_row;
+    KcRow<HS_A_KC> b_row;
+    RcCol a_col, b_col;
+    if constexpr (!A_RC) kc_row_setup<AK>(a, m0 + tid % BM, a_row);
+    else rc_col_setup<AK, true>(a, m0 + (tid % (BM / 4)) * 4, a_col);
+    if constexpr (!B_RC) {
+        const int n = n0 + tid % BN;
+        b_row.valid = n < a.N;
+        b_row.base = n * a.ldb;
+        b_row.hb = b_row.wb = 0;
+    } else {
+        rc_col_setup<BKIND, false>(a, n0 + (tid % (BN / 4)) * 4, b_col);
+    }
+
+    u32x4 a_reg[A_NCH], b_reg[B_NCH];
+    auto stage_load = [&](int k0) {
+        KTile kta = {0, 0, 0}, ktb = {0, 0, 0};
+        if constexpr (AK == HS_A_CONV) kta = ktile_rsc(k0, a.g.C, a.g.S);
+        if constexpr (AK == HS_A_DGRAD) kta = ktile_rsc(k0, a.g.K, a.g.S);
+        if constexpr (BKIND == HS_B_WDGRAD) ktb = ktile_rsc(k0, a.g.K, a.g.S);
+#pragma unroll
+        for (int i = 0; i < A_NCH; ++i) {
+            const int id = tid + 256 * i;
+            unsigned off;
+            int nvalid = 4;
+            if constexpr (!A_RC) {
+                const int k = k0 + (id / BM) * 4;
+                off = kc_chunk_off<AK, ESZ>(a, a_row, kta, k, kend);
+                nvalid = kend - k;
+            } else {
+                const int k = k0 + id / (BM / 4);
+                off = rc_chunk_off<AK, true, ESZ>(a, a_col, kta, k, kend);
+                if constexpr (!VEC) nvalid = a.M - a_col.base;
+            }
+            a_reg[i] = load_chunk<T>(rsA, off, VEC, nvalid);
+            if constexpr (!A_RC && VEC) if (nvalid < 4 && nvalid > 0) mask_tail<T>(a_reg[i], nvalid);
+        }
+#pragma unroll
+        for (int i = 0; i < B_NCH; ++i) {
+            const int id = tid + 256 * i;
+            unsigned off;
+            int nvalid = 4;
+            if constexpr (!B_RC) {
+                const int k = k0 + (id / BN) * 4;
+                off = kc_chunk_off<HS_A_KC, ESZ>(a, b_row, ktb, k, kend);
+                nvalid = kend - k;
+            } else {
+                const int k = k0 + id / (BN / 4);
+                off = rc_chunk_off<BKIND, false, ESZ>(a, b_col, ktb, k, kend);
+                if constexpr (!VEC) nvalid = a.N - (n0 + (tid % (BN / 4)) * 4);
+            }
+            b_reg[i] = load_chunk<T>(rsB, off, VEC, nvalid);
+            if constexpr (!B_RC && VEC) if (nvalid < 4 && nvalid > 0) mask_tail<T>(b_reg[i], nvalid);
+        }
+    };
+    auto stage_write = [&](int buf) {
+        float* sa = (float*)(smem + buf * STAGE);
+        float* sb = (float*)(smem + buf * STAGE + A_BYTES);
+#pragma unroll
+        for (int i = 0; i < A_NCH; ++i) {
+            const int id = tid + 256 * i;
+            if constexpr (!A_RC) {
+                const int r = id % BM, kc = id / BM;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sa[(kc * 4 + j) * BM + r] = __uint_as_float(a_reg[i][j]);
+            } else {
+                *(u32x4*)(sa + (id / (BM / 4)) * BM + (id % (BM / 4)) * 4) = a_reg[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_NCH; ++i) {
+            const int id = tid + 256 * i;
+            if constexpr (!B_RC) {
+                const int r = id % BN, kc = id / BN;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sb[(kc * 4 + j) * BN + r] = __uint_as_float(b_reg[i][j]);
+            } else {
+                *(u32x4*)(sb + (id / (BN / 4)) * BN + (id % (BN / 4)) * 4) = b_reg[i];
+            }
+        }
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int ntiles = (kend - kbeg + BK - 1) / BK;
+    if (ntiles > 0) {
+        stage_load(kbeg);
+        stage_write(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) stage_load(kbeg + (t + 1) * BK);
+        const float* sa = (const float*)(smem + cur * STAGE);
+        const float* sb = (const float*)(smem + cur * STAGE + A_BYTES);
+#pragma unroll 4
+        for (int kk = 0; kk < BK; kk += 2) {
+            float av[FM], bv[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) av[i] = sa[(kk + hh) * BM + wm * WM + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bv[j] = sb[(kk + hh) * BN + wn * WN + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j], av[i], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < ntiles) stage_write(cur ^ 1);
+        __syncthreads();
+    }
+
+    // lane owns m = .. + l31; register e -> n = 8*(e>>2) + 4*hh + (e&3)
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * WM + i * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int n = n0 + wn * WN + j * 32 + 8 * qd + 4 * hh;
+                float v[4] = {acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]};
+                if (a.split_k > 1) {
+                    if (m < a.M && n < a.N) {
+                        float* w = a.splitk_ws + ((long long)z * a.M + m) * a.N + n;
+                        if (n + 3 < a.N && (a.N & 3) == 0) *(f32x4*)w = f32x4{v[0], v[1], v[2], v[3]};
+                        else
+                            for (int e = 0; e < 4 && n + e < a.N; ++e) w[e] = v[e];
+                    }
+                } else {
+                    epilogue4<T>(a, d_boff, z, m, n, v);
+                }
+            }
+        }
+    }
+}
+
+// split-K second pass: sum the slabs in a fixed order (deterministic) and apply the epilogue.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
+    const long long nq = ((long long)a.N + 3) / 4;
+    const long long total = (long long)a.M * nq;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / nq), n = (int)(i - (long long)m * nq) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const int nvalid = min(4, a.N - n);
+        for (int s = 0; s < a.split_k; ++s) {
+            const float* w = a.splitk_ws + ((long long)s * a.M + m) * a.N + n;
+            if (nvalid == 4 && (a.N & 3) == 0) {
+                f32x4 x = *(const f32x4*)w;
+                v[0] += x[0]; v[1] += x[1]; v[2] += x[2]; v[3] += x[3];
+            } else {
+                for (int e = 0; e < nvalid; ++e) v[e] += w[e];
+            }
+        }
+        epilogue4<T>(a, 0, 0, m, n, v);
+    }
+}
+
+}  // namespace hs

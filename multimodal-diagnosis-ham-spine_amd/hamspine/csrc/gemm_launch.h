@@ -1,0 +1,23 @@
+// per-translation-unit launchers of the GEMM core (split so that `make -j` compiles them in parallel)
+#pragma once
+#include "gemm_core.h"
+namespace hs {
+enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_STEM = 3 };
+// combos: 0 (KC,KC) 1 (KC,RC) 2 (RC,RC) 3 (CONV,KC) 4 (DGRAD,WDGRAD) 5 (RC,CONV)
+int launch_bf16_plain(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s);
+int launch_bf16_conv(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s);
+int launch_f32_plain(int cfg, int combo, bool vec, const GemmArgs& a, dim3 grid, hipStream_t s);
+int launch_f32_conv(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s);
+
+bool lds_attr_needed(const void* fn);   // true the first time a kernel pointer is seen (thread safe)
+
+template <typename K>
+inline int launch_with_lds(K kernel, int lds, const GemmArgs& a, dim3 grid, hipStream_t s) {
+    if (lds >= 48 * 1024 && lds_attr_needed((const void*)kernel)) {
+        HS_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, a);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+}  // namespace hs

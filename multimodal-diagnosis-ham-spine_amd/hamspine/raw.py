@@ -1,0 +1,96 @@
+"""Thin torch-tensor wrappers over the C ABI (include/hamspine.h).  torch is plumbing here: device
+memory (tensors), the current HIP stream, nothing else.  No function in this file computes on the CPU.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def hs_dtype(t):
+    if t.dtype == torch.bfloat16:
+        return L.HS_BF16
+    if t.dtype == torch.float32:
+        return L.HS_F32
+    raise L.HamspineError(f"unsupported dtype {t.dtype}")
+
+
+def need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise L.HamspineError(
+                "hamspine kernels only run on the HIP device (tensor on %s); there is no CPU fallback" % t.device)
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def conv_geom(N, H, W, Cin, Kout, R, S, stride, pad, row_pitch=None, img_pitch=None, qstep=None,
+              no_bounds=0, P=None, Q=None):
+    g = L.ConvGeom()
+    g.N, g.H, g.W, g.C = N, H, W, Cin
+    g.P = (H + 2 * pad - R) // stride + 1 if P is None else P
+    g.Q = (W + 2 * pad - S) // stride + 1 if Q is None else Q
+    g.K, g.R, g.S, g.stride, g.pad = Kout, R, S, stride, pad
+    g.row_pitch = W * Cin if row_pitch is None else row_pitch
+    g.img_pitch = H * g.row_pitch if img_pitch is None else img_pitch
+    g.qstep = stride * Cin if qstep is None else qstep
+    g.no_bounds = no_bounds
+    return g
+
+
+def gemm(A, B, D, M, N, K, a_kind=L.A_KC, b_kind=L.B_KC, lda=0, ldb=0, ldd=None, geom=None,
+         batch=1, batch_inner=1, a_bs=(0, 0), b_bs=(0, 0), d_bs=(0, 0), split_k=1,
+         alpha=1.0, bias=None, act=L.ACT_NONE, preact=None, residual=None, ldr=None,
+         dropout_p=0.0, dropout_seed=0, mul_mode=L.MUL_NONE, mul_src=None, ldm=None, accumulate=False):
+    """D[m][n] = epi(alpha * sum_k A(m,k) B(n,k)); see include/hamspine.h for the operand kinds."""
+    need_gpu(A, B, D, bias, preact, residual, mul_src)
+    p = L.GemmParams()
+    p.dtype = hs_dtype(A)
+    if hs_dtype(B) != p.dtype:
+        raise L.HamspineError("gemm: A and B dtypes differ")
+    p.a_kind, p.b_kind = a_kind, b_kind
+    p.M, p.N, p.K = M, N, K
+    p.A, p.B = ptr(A), ptr(B)
+    p.a_elems, p.b_elems = A.numel(), B.numel()
+    p.lda, p.ldb = lda, ldb
+    if geom is not None:
+        p.g = geom
+    p.batch, p.batch_inner = batch, batch_inner
+    p.a_bs0, p.a_bs1 = a_bs
+    p.b_bs0, p.b_bs1 = b_bs
+    p.d_bs0, p.d_bs1 = d_bs
+    p.split_k = split_k
+    ws = None
+    if split_k > 1:
+        ws = torch.empty(split_k * M * N, dtype=torch.float32, device=A.device)
+        p.splitk_ws = ptr(ws)
+    p.D = ptr(D)
+    p.ldd = N if ldd is None else ldd
+    p.out_dtype = hs_dtype(D)
+    p.alpha = alpha
+    if bias is not None and bias.dtype != torch.float32:
+        raise L.HamspineError("gemm: bias must be f32")
+    p.bias = ptr(bias)
+    p.act = act
+    p.D_preact = ptr(preact)
+    p.residual = ptr(residual)
+    p.ldr = p.ldd if ldr is None else ldr
+    p.dropout_p = dropout_p
+    p.dropout_seed = dropout_seed
+    p.mul_mode = mul_mode
+    p.mul_src = ptr(mul_src)
+    p.ldm = p.ldd if ldm is None else ldm
+    p.accumulate = 1 if accumulate else 0
+    L.check(L.lib().hs_gemm(C.byref(p), stream_ptr()), "hs_gemm")
+    return D
+
+
+def suggest_split(M, N, K, dtype):
+    return int(L.lib().hs_gemm_suggest_split(M, N, K, dtype))

@@ -1,0 +1,168 @@
+"""Parity of the MFMA GEMM / implicit-GEMM conv core (C ABI hs_gemm) against float64 torch on the CPU.
+
+bf16 cases are fed integer-valued data where exactness is checked (catches layout / transpose bugs
+bit-exactly) and random data with a tolerance that is stated next to each assert."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import hamspine._lib as L  # noqa: E402
+from hamspine import raw  # noqa: E402
+
+DEV = "cuda"
+
+
+def _rand(shape, dtype, ints=False, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    if ints:
+        x = torch.randint(-3, 4, shape, generator=g).float()
+    else:
+        x = torch.randn(shape, generator=g)
+    return x.to(dtype)
+
+
+def _tol(dtype, K):
+    # f32: exact fmaf chain, only summation order differs from the CPU -> 1e-5 relative to |a|.|b|
+    # bf16: inputs are rounded to bf16 on both sides (the reference uses the rounded values), f32
+    # accumulation -> same bound; outputs stored as bf16 add 2^-8 relative.
+    return 2e-5 if dtype == torch.float32 else 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("combo", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (200, 136, 72), (4096, 768, 768), (64, 8, 256), (33, 48, 40)])
+def test_gemm_layouts(dtype, combo, shape):
+    M, N, K = shape
+    for ints in (True, False):
+        if combo == "nt":
+            A = _rand((M, K), dtype, ints, 1)
+            B = _rand((N, K), dtype, ints, 2)
+            ref = A.double() @ B.double().t()
+            kinds = (L.A_KC, L.B_KC, K, K)
+        elif combo == "nn":
+            A = _rand((M, K), dtype, ints, 1)
+            B = _rand((K, N), dtype, ints, 2)
+            ref = A.double() @ B.double()
+            kinds = (L.A_KC, L.B_RC, K, N)
+        else:
+            A = _rand((K, M), dtype, ints, 1)
+            B = _rand((K, N), dtype, ints, 2)
+            ref = A.double().t() @ B.double()
+            kinds = (L.A_RC, L.B_RC, M, N)
+        if dtype == torch.bfloat16 and (kinds[2] % 8 or kinds[3] % 8):
+            pytest.skip("bf16 path requires 16-byte aligned rows")
+        D = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+        raw.gemm(A.to(DEV), B.to(DEV), D, M, N, K, a_kind=kinds[0], b_kind=kinds[1], lda=kinds[2], ldb=kinds[3])
+        out = D.cpu().double()
+        if ints:
+            assert torch.equal(out, ref), f"{combo} {shape} {dtype}: integer data must be exact"
+        else:
+            scale = (A.double().abs().max() * B.double().abs().max() * K)
+            assert (out - ref).abs().max() <= _tol(dtype, K) * scale
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogue_and_splitk(dtype):
+    M, N, K = 256, 192, 512
+    A = _rand((M, K), dtype, False, 3)
+    B = _rand((N, K), dtype, False, 4)
+    bias = _rand((N,), torch.float32, False, 5)
+    res = _rand((M, N), dtype, False, 6)
+    pre_ref = 0.5 * (A.double() @ B.double().t()) + bias.double()
+    ref = torch.nn.functional.gelu(pre_ref) + res.double()
+    D = torch.empty((M, N), dtype=dtype, device=DEV)
+    P = torch.empty((M, N), dtype=dtype, device=DEV)
+    raw.gemm(A.to(DEV), B.to(DEV), D, M, N, K, lda=K, ldb=K, alpha=0.5, bias=bias.to(DEV), act=L.ACT_GELU,
+             preact=P, residual=res.to(DEV))
+    rel = 1e-5 if dtype == torch.float32 else 2.0 ** -7   # bf16 storage rounding of output
+    assert (D.cpu().double() - ref).abs().max() <= rel * ref.abs().max() + 1e-5
+    assert (P.cpu().double() - pre_ref).abs().max() <= rel * pre_ref.abs().max() + 1e-5
+    # split-K (deterministic slabs) == single pass up to f32 summation order
+    D1 = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    D4 = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    raw.gemm(A.to(DEV), B.to(DEV), D1, M, N, K, lda=K, ldb=K, bias=bias.to(DEV))
+    raw.gemm(A.to(DEV), B.to(DEV), D4, M, N, K, lda=K, ldb=K, bias=bias.to(DEV), split_k=4)
+    assert (D1 - D4).abs().max().item() <= 1e-4 * D1.abs().max().item()
+    # relu mask + gelu grad multipliers
+    u = _rand((M, N), dtype, False, 7)
+    Dm = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    raw.gemm(A.to(DEV), B.to(DEV), Dm, M, N, K, lda=K, ldb=K, mul_mode=L.MUL_RELU_MASK, mul_src=u.to(DEV))
+    ref_m = (A.double() @ B.double().t()) * (u.double() > 0)
+    assert (Dm.cpu().double() - ref_m).abs().max() <= 2e-5 * K * 16
+    raw.gemm(A.to(DEV), B.to(DEV), Dm, M, N, K, lda=K, ldb=K, mul_mode=L.MUL_GELU_GRAD, mul_src=u.to(DEV))
+    ud = u.double().requires_grad_(True)
+    torch.nn.functional.gelu(ud).sum().backward()
+    ref_g = (A.double() @ B.double().t()) * ud.grad
+    assert (Dm.cpu().double() - ref_g).abs().max() <= 1e-4 * ref_g.abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_batched_and_dropout(dtype):
+    Bt, H, Lq, Lk, d = 3, 4, 49, 128, 32
+    q = _rand((Bt, Lq, H * d), dtype, False, 1)
+    k = _rand((Bt, Lk, H * d), dtype, False, 2)
+    S = torch.empty((Bt, H, Lq, Lk), dtype=torch.float32, device=DEV)
+    raw.gemm(q.to(DEV), k.to(DEV), S, Lq, Lk, d, lda=H * d, ldb=H * d, ldd=Lk, batch=Bt * H, batch_inner=H,
+             a_bs=(Lq * H * d, d), b_bs=(Lk * H * d, d), d_bs=(H * Lq * Lk, Lq * Lk), alpha=0.25)
+    ref = 0.25 * torch.einsum("bqhd,bkhd->bhqk", q.double().view(Bt, Lq, H, d), k.double().view(Bt, Lk, H, d))
+    assert (S.cpu().double() - ref).abs().max() <= 1e-4 * ref.abs().max()
+    # dropout: deterministic in (seed, index); keep-rate ~ 1-p; kept values scaled by 1/(1-p)
+    M, N, K = 512, 256, 64
+    A = _rand((M, K), dtype, False, 3)
+    Bm = _rand((N, K), dtype, False, 4)
+    D0 = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    D1 = torch.empty_like(D0)
+    D2 = torch.empty_like(D0)
+    raw.gemm(A.to(DEV), Bm.to(DEV), D0, M, N, K, lda=K, ldb=K)
+    raw.gemm(A.to(DEV), Bm.to(DEV), D1, M, N, K, lda=K, ldb=K, dropout_p=0.1, dropout_seed=1234)
+    raw.gemm(A.to(DEV), Bm.to(DEV), D2, M, N, K, lda=K, ldb=K, dropout_p=0.1, dropout_seed=1234)
+    assert torch.equal(D1, D2)
+    kept = D1 != 0
+    frac = kept.float().mean().item()
+    assert abs(frac - 0.9) < 0.01
+    assert torch.allclose(D1[kept], D0[kept] / 0.9, rtol=1e-6, atol=1e-6)
+
+
+CONV_CASES = [
+    # N, C, H, W, K, R, stride, pad
+    (2, 64, 14, 14, 64, 3, 1, 1),
+    (2, 64, 15, 13, 128, 3, 2, 1),
+    (3, 128, 8, 8, 256, 1, 1, 0),
+    (2, 256, 14, 14, 512, 1, 2, 0),
+    (4, 64, 56, 56, 64, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(dtype, case):
+    N, Cin, H, W, K, R, stride, pad = case
+    x = _rand((N, Cin, H, W), dtype, False, 1)
+    w = (_rand((K, Cin, R, R), dtype, False, 2) * 0.1).to(dtype)
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    yref = torch.nn.functional.conv2d(xd, wd, stride=stride, padding=pad)
+    P, Q = yref.shape[2:]
+    dy = _rand(tuple(yref.shape), dtype, False, 3)
+    yref.backward(dy.double())
+    g = raw.conv_geom(N, H, W, Cin, K, R, R, stride, pad)
+    xg = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    wg = w.to(DEV).contiguous(memory_format=torch.channels_last)
+    dyg = dy.to(DEV).contiguous(memory_format=torch.channels_last)
+    RSC = R * R * Cin
+    tol = 2e-5 if dtype == torch.float32 else 2e-5
+    # forward
+    y = torch.empty((N, K, P, Q), dtype=torch.float32, device=DEV).contiguous(memory_format=torch.channels_last)
+    raw.gemm(xg, wg, y, N * P * Q, K, RSC, a_kind=L.A_CONV, b_kind=L.B_KC, ldb=RSC, ldd=K, geom=g)
+    assert (y.cpu().double() - yref.detach()).abs().max() <= tol * RSC * x.abs().max().item() * w.abs().max().item()
+    # dgrad
+    dx = torch.empty((N, Cin, H, W), dtype=torch.float32, device=DEV).contiguous(memory_format=torch.channels_last)
+    raw.gemm(dyg, wg, dx, N * H * W, Cin, R * R * K, a_kind=L.A_DGRAD, b_kind=L.B_WDGRAD, ldd=Cin, geom=g)
+    assert (dx.cpu().double() - xd.grad).abs().max() <= tol * R * R * K * dy.abs().max().item() * w.abs().max().item()
+    # wgrad (with and without split-K)
+    for split in (1, 3):
+        dw = torch.empty((K, Cin, R, R), dtype=torch.float32, device=DEV).contiguous(memory_format=torch.channels_last)
+        raw.gemm(dyg, xg, dw, K, RSC, N * P * Q, a_kind=L.A_RC, b_kind=L.B_CONV, lda=K, ldd=RSC, geom=g,
+                 split_k=split)
+        assert (dw.cpu().double() - wd.grad).abs().max() <= tol * N * P * Q * dy.abs().max().item() * x.abs().max().item()
