@@ -110,6 +110,261 @@ int64_t hs_gemm_splitk_ws_bytes(const hs_gemm_params* p);
 /* heuristic split-K factor for a (M,N,K) problem so that the grid fills 256 CUs. */
 int32_t hs_gemm_suggest_split(int32_t M, int32_t N, int32_t K, int32_t dtype);
 
+/* ------------------------------------------------------------------------------------------- */
+/* BatchNorm2d over NHWC activations viewed as [M = N*H*W][C]                                    */
+/* Replaces torch.nn.BatchNorm2d inside torchvision ResNet blocks (reference encoder.py:35-42,  */
+/* mibf_net/model_resnet.py:15): train mode = batch statistics (biased var for normalisation,   */
+/* unbiased for running_var, momentum 0.1), eval mode = running statistics.                     */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct hs_bn_params {
+    int32_t dtype;
+    int32_t C;
+    int64_t M;
+    int32_t training;        /* 1: batch stats (+ running update), 0: running stats              */
+    int32_t relu;            /* fuse ReLU into the apply pass                                    */
+    float eps, momentum;
+    const void* x;           /* [M][C]                                                           */
+    const void* residual;    /* optional [M][C], added before the ReLU                           */
+    void* y;                 /* [M][C] (NULL: statistics only)                                   */
+    const float* gamma;
+    const float* beta;
+    float* running_mean;     /* may be NULL in training (no update)                              */
+    float* running_var;
+    float* save_mean;        /* [C] out                                                          */
+    float* save_invstd;      /* [C] out                                                          */
+    float* scale;            /* [C] out: gamma*invstd                                            */
+    float* shift;            /* [C] out: beta - mean*gamma*invstd                                */
+    void* ws;                /* hs_batchnorm_ws_bytes(M, C, dtype)                               */
+    int64_t ws_bytes;
+} hs_bn_params;
+
+typedef struct hs_bn_bwd_params {
+    int32_t dtype;
+    int32_t C;
+    int64_t M;
+    int32_t training;
+    int32_t relu;            /* forward fused a ReLU: dz = dy * (y > 0)                          */
+    const void* dy;
+    const void* y;           /* forward output (needed when relu)                                */
+    const void* x;           /* forward input                                                    */
+    const float* gamma;
+    const float* save_mean;
+    const float* save_invstd;
+    void* dx;                /* [M][C] (NULL: parameter gradients only)                          */
+    void* dres;              /* optional: gradient of the residual input (= dz)                  */
+    float* dgamma;
+    float* dbeta;
+    void* ws;
+    int64_t ws_bytes;
+} hs_bn_bwd_params;
+
+hs_status hs_batchnorm_fwd(const hs_bn_params* p, void* stream);
+hs_status hs_batchnorm_bwd(const hs_bn_bwd_params* p, void* stream);
+int64_t hs_batchnorm_ws_bytes(int64_t M, int32_t C, int32_t dtype);
+
+/* LayerNorm over the last dim of [M][H]. Replaces torch.nn.LayerNorm (reference                */
+/* modules/fusion_blocks.py:17-34, modules/heads.py:36; transformers Bert*Output.LayerNorm).    */
+hs_status hs_layernorm_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y,
+                           float* mean, float* rstd, int64_t M, int32_t H, float eps, void* stream);
+hs_status hs_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                           const float* rstd, void* dx, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes,
+                           int64_t M, int32_t H, void* stream);
+int64_t hs_layernorm_bwd_ws_bytes(int64_t M, int32_t H);
+
+/* ------------------------------------------------------------------------------------------- */
+/* pooling, packing, casts, reductions, softmax, embeddings, loss, optimizer (HBM-bound helpers) */
+/* ------------------------------------------------------------------------------------------- */
+#define HS_CAST_MAX 48
+#define HS_ADAM_MAX 32
+
+/* MaxPool2d(k, s, p) on NHWC; idx (uint8, same shape as y) keeps the arg-max tap for the backward.
+   Replaces torchvision ResNet.maxpool (reference encoder.py:67). */
+hs_status hs_maxpool_fwd(int32_t dtype, const void* x, void* y, void* idx, int32_t N, int32_t H, int32_t W, int32_t C,
+                         int32_t ksize, int32_t stride, int32_t pad, void* stream);
+hs_status hs_maxpool_bwd(int32_t dtype, const void* dy, const void* idx, void* dx, int32_t N, int32_t H, int32_t W,
+                         int32_t C, int32_t ksize, int32_t stride, int32_t pad, void* stream);
+/* y[b][:] = mean_t x[b][t][:]  (AdaptiveAvgPool / tokens.mean(dim=1); reference
+   modules/fusion_blocks.py:97-98,170-178, model.py:283-290, torchvision ResNet.avgpool). */
+hs_status hs_mean_tokens_fwd(int32_t dtype, const void* x, void* y, int32_t B, int32_t Nt, int32_t H, int32_t out_f32,
+                             void* stream);
+hs_status hs_mean_tokens_bwd(int32_t dtype, const void* dy, void* dx, int32_t B, int32_t Nt, int32_t H, int32_t dy_f32,
+                             void* stream);
+/* f32 NCHW image -> zero-bordered NHWC4 image of type dtype: [N][Hp][Wp][4], pixel (h,w) at (h+pad, w+pad). */
+hs_status hs_pack_image(int32_t dtype, const float* x, void* y, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Hp,
+                        int32_t Wp, int32_t pad, void* stream);
+/* stem filter [K][R][S][Cin] f32 (channels_last storage of (K,Cin,R,S)) <-> packed [K][R][8][4]. */
+hs_status hs_pack_stem_weight(int32_t dtype, const float* w, void* out, int32_t K, int32_t R, int32_t S, int32_t Cin,
+                              void* stream);
+hs_status hs_unpack_stem_wgrad(const float* g, float* dw, int32_t K, int32_t R, int32_t S, int32_t Cin, void* stream);
+/* one launch per HS_CAST_MAX tensors: dst[i] (bf16) = src[i] (f32). */
+hs_status hs_cast_f32_to_bf16_multi(int32_t count, const float* const* src, void* const* dst, const int64_t* n,
+                                    void* stream);
+/* out = a*x + b*y (y may be NULL); dtypes are HS_F32/HS_BF16 for inputs (shared) and output. */
+hs_status hs_axpby(int32_t in_dtype, int32_t out_dtype, const void* x, const void* y, void* out, int64_t n, float a,
+                   float b, void* stream);
+/* out[i] = x[i] * keep(seed, i) / (1-p): the same call is its own backward. */
+hs_status hs_dropout(int32_t dtype, const void* x, void* out, int64_t n, float p, uint64_t seed, void* stream);
+hs_status hs_relu_fwd(int32_t dtype, const void* x, void* out, int64_t n, void* stream);
+hs_status hs_relu_bwd(int32_t dtype, const void* dy, const void* y, void* dx, int64_t n, void* stream);
+/* out[n] (+)= sum_m x[m*ld + n]  (bias gradients). */
+hs_status hs_colsum(int32_t dtype, const void* x, int64_t M, int32_t N, int32_t ld, float* out, void* ws,
+                    int64_t ws_bytes, int32_t accumulate, void* stream);
+int64_t hs_colsum_ws_bytes(int64_t M, int32_t N);
+/* attention probabilities from materialised f32 scores; rows = (b,h,q); mask[b][k] == 0 masks key k.
+   P gets the probabilities (padding columns Lk..ldP-1 zeroed), P_drop (optional) the dropped-out copy. */
+hs_status hs_softmax_fwd(int32_t dtype, const float* S, const int64_t* mask, void* P, void* P_drop, int64_t rows,
+                         int32_t Lk, int32_t ldS, int32_t ldP, int32_t rows_per_batch, float dropout_p, uint64_t seed,
+                         void* stream);
+hs_status hs_softmax_bwd(int32_t dtype, const float* dP, const void* P, void* dS, int64_t rows, int32_t Lk, int32_t ldG,
+                         int32_t ldP, float dropout_p, uint64_t seed, void* stream);
+/* BertEmbeddings (token_type_ids == 0): sum_out = word[ids]+pos[l]+type0 ; y = dropout(LN(sum_out)). */
+hs_status hs_bert_embed_fwd(int32_t dtype, const int64_t* ids, const float* word, const float* pos, const float* type0,
+                            const float* gamma, const float* beta, void* sum_out, void* y, float* mean, float* rstd,
+                            int64_t tokens, int32_t L, int32_t H, int32_t V, float eps, float dropout_p, uint64_t seed,
+                            void* stream);
+/* dword (zero-filled by the caller) += scatter(dsum by ids); dpos[l] = sum_b dsum[b][l]. */
+hs_status hs_bert_embed_bwd(int32_t dtype, const int64_t* ids, const void* dsum, float* dword, float* dpos, int32_t B,
+                            int32_t L, int32_t H, int32_t V, void* stream);
+/* mean-reduced CrossEntropyLoss(weight, label_smoothing): writes the scalar loss, d loss / d logits
+   (optional) and the per-row unreduced losses (optional). reference scripts/train.py:240,252-254. */
+hs_status hs_cross_entropy(const float* logits, const int64_t* labels, const float* weight, float label_smoothing,
+                           int32_t B, int32_t C, float* loss, float* dlogits, float* row_loss, void* stream);
+/* fused multi-tensor Adam (decoupled=0) / AdamW (decoupled=1) step over f32 tensors. */
+hs_status hs_adam_step_multi(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                             float* const* exp_avg_sq, const int64_t* n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int32_t step, int32_t decoupled, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Composite executors: one call = one nn.Module forward (or backward) of the reference's module  */
+/* tree, launched from C++ so the Python host issues O(10) calls per step instead of O(1000).     */
+/* Every composite has a *_query that returns the bytes of `saved` (activations kept for the      */
+/* backward, also used as forward temporaries) and `ws` (scratch) it needs for a given descriptor. */
+/* The caller allocates both; `saved` must be passed unchanged to the matching backward.          */
+/* ------------------------------------------------------------------------------------------- */
+
+/* multi-head attention core on projected q/k/v (materialised scores):
+     S = scale * Q K^T (+ key mask) ; P = softmax(S) ; O = dropout(P) V
+   q/k/v/o element (b, t, h, j) lives at  base + b*bs + t*ld + h*hd + j.
+   Replaces the attention inside torch.nn.MultiheadAttention (reference modules/fusion_blocks.py:
+   18-31,107-112; modules/heads.py:86) and transformers BertSelfAttention (encoder.py:131). */
+typedef struct hs_attn_desc {
+    int32_t dtype;
+    int32_t B, H, Lq, Lk, hd;      /* batch, heads, query len, key len, head dim                  */
+    int64_t q_bs, k_bs, v_bs, o_bs;/* batch strides (elements)                                    */
+    int32_t q_ld, k_ld, v_ld, o_ld;/* token strides (elements)                                    */
+    float scale;
+    float dropout_p;
+    uint64_t seed;
+    const int64_t* key_mask;       /* [B][Lk], 0 = masked key; NULL = no mask                     */
+} hs_attn_desc;
+hs_status hs_attention_query(const hs_attn_desc* d, int64_t* saved_bytes, int64_t* ws_bytes);
+hs_status hs_attention_fwd(const hs_attn_desc* d, const void* q, const void* k, const void* v, void* o, void* saved,
+                           int64_t saved_bytes, void* ws, int64_t ws_bytes, void* stream);
+/* dq/dk/dv use the q/k/v strides of the descriptor; do uses the o strides. */
+hs_status hs_attention_bwd(const hs_attn_desc* d, const void* q, const void* k, const void* v, const void* d_o, void* dq,
+                           void* dk, void* dv, void* saved, int64_t saved_bytes, void* ws, int64_t ws_bytes,
+                           void* stream);
+
+/* conv + BatchNorm pair of a residual block. `w` is the f32 filter stored KRSC (channels_last). */
+typedef struct hs_conv_bn {
+    int32_t Cin, Cout, R, stride, pad;
+    const float* w;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    float* dw;        /* backward outputs (f32); NULL = frozen parameter, wgrad skipped            */
+    float* dgamma;
+    float* dbeta;
+} hs_conv_bn;
+
+/* torchvision BasicBlock (n_main = 2: 3x3,3x3) / Bottleneck (n_main = 3: 1x1,3x3[stride],1x1) with an
+   optional 1x1 downsample branch: y = relu(main(x) + (ds ? bn(conv(x)) : x)).
+   Replaces torchvision.models.resnet.{BasicBlock,Bottleneck}.forward under reference
+   encoder.py:69-72 and mibf_net/model_resnet.py:15. */
+typedef struct hs_resblock_desc {
+    int32_t dtype;
+    int32_t N, H, W;              /* input image; channels = main[0].Cin                           */
+    int32_t training;             /* BatchNorm mode                                                */
+    float eps, momentum;
+    int32_t n_main;
+    hs_conv_bn main[3];
+    int32_t has_ds;
+    hs_conv_bn ds;
+} hs_resblock_desc;
+hs_status hs_resblock_query(const hs_resblock_desc* d, int64_t* saved_bytes, int64_t* ws_bytes);
+hs_status hs_resblock_fwd(const hs_resblock_desc* d, const void* x, void* y, void* saved, int64_t saved_bytes, void* ws,
+                          int64_t ws_bytes, void* stream);
+/* dx may be NULL (no input gradient wanted). */
+hs_status hs_resblock_bwd(const hs_resblock_desc* d, const void* x, const void* y, const void* dy, void* dx, void* saved,
+                          int64_t saved_bytes, void* ws, int64_t ws_bytes, void* stream);
+
+/* ResNet stem: conv7x7/2 (3->64) + BN + ReLU + maxpool3x3/2 on an f32 NCHW image.
+   Replaces reference encoder.py:63-68 (self.stem) / torchvision ResNet conv1..maxpool. */
+typedef struct hs_stem_desc {
+    int32_t dtype;
+    int32_t N, H, W;              /* input image (3 channels, f32 NCHW)                            */
+    int32_t training;
+    float eps, momentum;
+    hs_conv_bn cb;                /* Cin = 3, Cout = 64, R = 7, stride = 2, pad = 3                */
+} hs_stem_desc;
+hs_status hs_stem_query(const hs_stem_desc* d, int64_t* saved_bytes, int64_t* ws_bytes);
+hs_status hs_stem_fwd(const hs_stem_desc* d, const float* image, void* y, void* saved, int64_t saved_bytes, void* ws,
+                      int64_t ws_bytes, void* stream);
+hs_status hs_stem_bwd(const hs_stem_desc* d, const void* y, const void* dy, void* saved, int64_t saved_bytes, void* ws,
+                      int64_t ws_bytes, void* stream);
+
+/* Linear layer parameters (f32) and their gradient outputs. */
+typedef struct hs_linear {
+    int32_t in_f, out_f;
+    const float* w;               /* [out][in]                                                     */
+    const float* b;               /* [out] or NULL                                                 */
+    float* dw;                    /* NULL = frozen                                                 */
+    float* db;
+} hs_linear;
+typedef struct hs_norm {
+    const float* gamma;
+    const float* beta;
+    float* dgamma;
+    float* dbeta;
+} hs_norm;
+
+/* transformers BertLayer (post-LN, erf-GELU): self-attention + output dense/LN + FFN + output LN.
+   Replaces transformers.models.bert.modeling_bert.BertLayer.forward under reference
+   encoder.py:131, mibf_net/bert.py:12. */
+typedef struct hs_bert_layer_desc {
+    int32_t dtype;
+    int32_t B, L, hidden, heads, inter;
+    float ln_eps;
+    float hidden_dropout, attn_dropout;   /* 0 in eval mode                                         */
+    uint64_t seed;
+    const int64_t* attention_mask;        /* [B][L], 1 = attend                                     */
+    hs_linear q, k, v, ao;                /* attention.self.{query,key,value}, attention.output.dense */
+    hs_norm ln1;                          /* attention.output.LayerNorm                             */
+    hs_linear inter_l, out_l;             /* intermediate.dense, output.dense                       */
+    hs_norm ln2;                          /* output.LayerNorm                                       */
+} hs_bert_layer_desc;
+hs_status hs_bert_layer_query(const hs_bert_layer_desc* d, int64_t* saved_bytes, int64_t* ws_bytes);
+hs_status hs_bert_layer_fwd(const hs_bert_layer_desc* d, const void* x, void* y, void* saved, int64_t saved_bytes,
+                            void* ws, int64_t ws_bytes, void* stream);
+hs_status hs_bert_layer_bwd(const hs_bert_layer_desc* d, const void* x, const void* dy, void* dx, void* saved,
+                            int64_t saved_bytes, void* ws, int64_t ws_bytes, void* stream);
+
+/* y = act(x W^T + b) with optional dropout / residual; generic Linear fwd + bwd on [M][in] rows.
+   Replaces torch.nn.Linear call sites of the reference (encoder.py:80-86, modules/ *.py, model.py:195-200,
+   mibf_net/attention.py:40-45, mibf_net/model_resnet.py:16,22-34). */
+hs_status hs_linear_fwd(int32_t dtype, const void* x, int64_t M, int32_t ldx, const hs_linear* lin, const void* w_lp,
+                        void* y, int32_t ldy, int32_t out_dtype, int32_t act, void* preact, const void* residual,
+                        int32_t ldr, float dropout_p, uint64_t seed, void* stream);
+/* dx = (dy W) [* act'(preact)] ; dw/db per `lin` (skipped when NULL). `dy` must already include the
+   activation derivative when act != none (use mul_mode to fold it into this call's dx = ... of the
+   PREVIOUS layer instead).  ws: hs_linear_bwd_ws_bytes. */
+hs_status hs_linear_bwd(int32_t dtype, const void* x, int64_t M, int32_t ldx, const hs_linear* lin, const void* w_lp,
+                        const void* dy, int32_t ldy, void* dx, int32_t lddx, int32_t dx_dtype, int32_t mul_mode,
+                        const void* mul_src, int32_t ldm, const void* dx_residual, void* ws, int64_t ws_bytes,
+                        void* stream);
+int64_t hs_linear_bwd_ws_bytes(int64_t M, int32_t in_f, int32_t out_f, int32_t dtype);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,1028 @@
+// Composite executors: attention core, Linear fwd/bwd, ResNet residual block, ResNet stem and
+// BertLayer, each launched from C++ on top of the op-level ABI (hs_gemm, hs_batchnorm_*, ...).
+// Buffers come from two caller-provided arenas: `saved` (activations kept for the backward) and `ws`
+// (scratch).  The same layout code runs in "plan" mode (no launches) to answer the *_query calls, so
+// sizes and pointers cannot drift apart.
+#include <algorithm>
+#include "hs_common.h"
+
+namespace hs {
+
+int gemm_impl(const hs_gemm_params* p, hipStream_t stream);
+
+static inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
+static inline int esize(int dt) { return dt == HS_BF16 ? 2 : 4; }
+
+struct Arena {
+    char* base = nullptr;
+    long long cap = 0, off = 0, peak = 0;
+    bool plan = false;
+    bool overflow = false;
+    void* alloc(long long bytes) {
+        bytes = align_up(bytes > 0 ? bytes : 1, 256);
+        char* p = base ? base + off : nullptr;
+        off += bytes;
+        if (off > peak) peak = off;
+        if (!plan && off > cap) overflow = true;
+        return plan ? nullptr : p;
+    }
+    long long mark() const { return off; }
+    void release(long long m) { off = m; }
+};
+
+struct Run {
+    hipStream_t s;
+    int dt;
+    bool plan;
+    Arena saved, ws;
+};
+static void run_init(Run& r, int dt, bool plan, void* saved, long long saved_bytes, void* ws, long long ws_bytes,
+                     hipStream_t s) {
+    r.s = s;
+    r.dt = dt;
+    r.plan = plan;
+    r.saved.base = (char*)saved;
+    r.saved.cap = saved_bytes;
+    r.saved.plan = plan;
+    r.ws.base = (char*)ws;
+    r.ws.cap = ws_bytes;
+    r.ws.plan = plan;
+}
+#define RUN_CHECK_ARENAS(r, what)                                                                          \
+    do {                                                                                                   \
+        if (!(r).plan && ((r).saved.overflow || (r).ws.overflow)) {                                        \
+            set_error("%s: arena too small (saved %lld/%lld, ws %lld/%lld)", what, (r).saved.peak,          \
+                      (r).saved.cap, (r).ws.peak, (r).ws.cap);                                             \
+            return HS_ERR_ARG;                                                                             \
+        }                                                                                                  \
+    } while (0)
+#define CALL(r, expr)                        \
+    do {                                     \
+        if (!(r).plan) HS_PROPAGATE(expr);   \
+    } while (0)
+
+static hs_gemm_params gemm_defaults(int dt) {
+    hs_gemm_params p;
+    memset(&p, 0, sizeof(p));
+    p.dtype = dt;
+    p.out_dtype = dt;
+    p.alpha = 1.f;
+    p.batch = 1;
+    p.batch_inner = 1;
+    return p;
+}
+// wgrad-style GEMMs reduce over a long K into a small output: pick split-K, borrow slabs from ws.
+static int gemm_splitk(Run& r, hs_gemm_params& p) {
+    const int split = hs_gemm_suggest_split(p.M, p.N, p.K, p.dtype);
+    const long long mk = r.ws.mark();
+    p.split_k = split;
+    if (split > 1) p.splitk_ws = (float*)r.ws.alloc((long long)split * p.M * p.N * 4);
+    if (!r.plan) {
+        if (r.ws.overflow) {
+            set_error("gemm_splitk: workspace too small");
+            return HS_ERR_ARG;
+        }
+        HS_PROPAGATE(gemm_impl(&p, r.s));
+    }
+    r.ws.release(mk);
+    return HS_OK;
+}
+
+// ============================================================================================
+// attention core
+// ============================================================================================
+struct AttnLayout {
+    int ldP;
+    void *P, *Pd;        // saved
+    float* S;            // ws (forward) / dP (backward)
+    void* dS;            // ws (backward)
+};
+static AttnLayout attn_layout(const hs_attn_desc& d, Run& r, bool backward) {
+    AttnLayout l;
+    const long long BH = (long long)d.B * d.H;
+    l.ldP = (int)align_up(d.Lk, 8);
+    l.P = r.saved.alloc(BH * d.Lq * l.ldP * esize(d.dtype));
+    l.Pd = d.dropout_p > 0.f ? r.saved.alloc(BH * d.Lq * l.ldP * esize(d.dtype)) : l.P;
+    l.S = (float*)r.ws.alloc(BH * d.Lq * d.Lk * 4);
+    l.dS = backward ? r.ws.alloc(BH * d.Lq * l.ldP * esize(d.dtype)) : nullptr;
+    return l;
+}
+static int attn_check(const hs_attn_desc& d) {
+    HS_REQUIRE(d.B > 0 && d.H > 0 && d.Lq > 0 && d.Lk > 0 && d.hd > 0, "attention: bad dims");
+    HS_REQUIRE(d.Lk <= 1024, "attention: Lk=%d > 1024 unsupported", d.Lk);
+    return HS_OK;
+}
+static long long span_elems(int B, long long bs, int L, int ld, int H, int hd) {
+    return (long long)(B - 1) * bs + (long long)(L - 1) * ld + (long long)H * hd;
+}
+
+static int attention_fwd_run(Run& r, const hs_attn_desc& d, const void* q, const void* k, const void* v, void* o) {
+    HS_PROPAGATE(attn_check(d));
+    AttnLayout l = attn_layout(d, r, false);
+    const int BH = d.B * d.H;
+    // S = scale * Q K^T
+    hs_gemm_params p = gemm_defaults(d.dtype);
+    p.a_kind = HS_A_KC; p.b_kind = HS_B_KC;
+    p.M = d.Lq; p.N = d.Lk; p.K = d.hd;
+    p.A = q; p.B = k;
+    p.a_elems = span_elems(d.B, d.q_bs, d.Lq, d.q_ld, d.H, d.hd);
+    p.b_elems = span_elems(d.B, d.k_bs, d.Lk, d.k_ld, d.H, d.hd);
+    p.lda = d.q_ld; p.ldb = d.k_ld;
+    p.batch = BH; p.batch_inner = d.H;
+    p.a_bs0 = d.q_bs; p.a_bs1 = d.hd;
+    p.b_bs0 = d.k_bs; p.b_bs1 = d.hd;
+    p.d_bs0 = (long long)d.H * d.Lq * d.Lk; p.d_bs1 = (long long)d.Lq * d.Lk;
+    p.D = l.S; p.ldd = d.Lk; p.out_dtype = HS_F32;
+    p.alpha = d.scale;
+    CALL(r, gemm_impl(&p, r.s));
+    CALL(r, hs_softmax_fwd(d.dtype, l.S, d.key_mask, l.P, d.dropout_p > 0.f ? l.Pd : nullptr, (long long)BH * d.Lq, d.Lk,
+                           d.Lk, l.ldP, d.H * d.Lq, d.dropout_p, d.seed, r.s));
+    // O = Pd V
+    hs_gemm_params g = gemm_defaults(d.dtype);
+    g.a_kind = HS_A_KC; g.b_kind = HS_B_RC;
+    g.M = d.Lq; g.N = d.hd; g.K = d.Lk;
+    g.A = l.Pd; g.B = v;
+    g.a_elems = (long long)BH * d.Lq * l.ldP;
+    g.b_elems = span_elems(d.B, d.v_bs, d.Lk, d.v_ld, d.H, d.hd);
+    g.lda = l.ldP; g.ldb = d.v_ld;
+    g.batch = BH; g.batch_inner = d.H;
+    g.a_bs0 = (long long)d.H * d.Lq * l.ldP; g.a_bs1 = (long long)d.Lq * l.ldP;
+    g.b_bs0 = d.v_bs; g.b_bs1 = d.hd;
+    g.d_bs0 = d.o_bs; g.d_bs1 = d.hd;
+    g.D = o; g.ldd = d.o_ld;
+    CALL(r, gemm_impl(&g, r.s));
+    RUN_CHECK_ARENAS(r, "attention_fwd");
+    return HS_OK;
+}
+
+static int attention_bwd_run(Run& r, const hs_attn_desc& d, const void* q, const void* k, const void* v, const void* dO,
+                             void* dq, void* dk, void* dv) {
+    HS_PROPAGATE(attn_check(d));
+    AttnLayout l = attn_layout(d, r, true);
+    const int BH = d.B * d.H;
+    const long long o_el = span_elems(d.B, d.o_bs, d.Lq, d.o_ld, d.H, d.hd);
+    const long long p_el = (long long)BH * d.Lq * l.ldP;
+    // dPd = dO V^T  (f32)
+    hs_gemm_params p = gemm_defaults(d.dtype);
+    p.a_kind = HS_A_KC; p.b_kind = HS_B_KC;
+    p.M = d.Lq; p.N = d.Lk; p.K = d.hd;
+    p.A = dO; p.B = v;
+    p.a_elems = o_el;
+    p.b_elems = span_elems(d.B, d.v_bs, d.Lk, d.v_ld, d.H, d.hd);
+    p.lda = d.o_ld; p.ldb = d.v_ld;
+    p.batch = BH; p.batch_inner = d.H;
+    p.a_bs0 = d.o_bs; p.a_bs1 = d.hd;
+    p.b_bs0 = d.v_bs; p.b_bs1 = d.hd;
+    p.d_bs0 = (long long)d.H * d.Lq * d.Lk; p.d_bs1 = (long long)d.Lq * d.Lk;
+    p.D = l.S; p.ldd = d.Lk; p.out_dtype = HS_F32;
+    CALL(r, gemm_impl(&p, r.s));
+    // dV = Pd^T dO
+    hs_gemm_params gv = gemm_defaults(d.dtype);
+    gv.a_kind = HS_A_RC; gv.b_kind = HS_B_RC;
+    gv.M = d.Lk; gv.N = d.hd; gv.K = d.Lq;
+    gv.A = l.Pd; gv.B = dO;
+    gv.a_elems = p_el; gv.b_elems = o_el;
+    gv.lda = l.ldP; gv.ldb = d.o_ld;
+    gv.batch = BH; gv.batch_inner = d.H;
+    gv.a_bs0 = (long long)d.H * d.Lq * l.ldP; gv.a_bs1 = (long long)d.Lq * l.ldP;
+    gv.b_bs0 = d.o_bs; gv.b_bs1 = d.hd;
+    gv.d_bs0 = d.v_bs; gv.d_bs1 = d.hd;
+    gv.D = dv; gv.ldd = d.v_ld;
+    CALL(r, gemm_impl(&gv, r.s));
+    // dS = softmax'(P, dPd)
+    CALL(r, hs_softmax_bwd(d.dtype, l.S, l.P, l.dS, (long long)BH * d.Lq, d.Lk, d.Lk, l.ldP, d.dropout_p, d.seed, r.s));
+    // dQ = scale * dS K
+    hs_gemm_params gq = gemm_defaults(d.dtype);
+    gq.a_kind = HS_A_KC; gq.b_kind = HS_B_RC;
+    gq.M = d.Lq; gq.N = d.hd; gq.K = d.Lk;
+    gq.A = l.dS; gq.B = k;
+    gq.a_elems = p_el;
+    gq.b_elems = span_elems(d.B, d.k_bs, d.Lk, d.k_ld, d.H, d.hd);
+    gq.lda = l.ldP; gq.ldb = d.k_ld;
+    gq.batch = BH; gq.batch_inner = d.H;
+    gq.a_bs0 = (long long)d.H * d.Lq * l.ldP; gq.a_bs1 = (long long)d.Lq * l.ldP;
+    gq.b_bs0 = d.k_bs; gq.b_bs1 = d.hd;
+    gq.d_bs0 = d.q_bs; gq.d_bs1 = d.hd;
+    gq.D = dq; gq.ldd = d.q_ld;
+    gq.alpha = d.scale;
+    CALL(r, gemm_impl(&gq, r.s));
+    // dK = scale * dS^T Q
+    hs_gemm_params gk = gemm_defaults(d.dtype);
+    gk.a_kind = HS_A_RC; gk.b_kind = HS_B_RC;
+    gk.M = d.Lk; gk.N = d.hd; gk.K = d.Lq;
+    gk.A = l.dS; gk.B = q;
+    gk.a_elems = p_el;
+    gk.b_elems = span_elems(d.B, d.q_bs, d.Lq, d.q_ld, d.H, d.hd);
+    gk.lda = l.ldP; gk.ldb = d.q_ld;
+    gk.batch = BH; gk.batch_inner = d.H;
+    gk.a_bs0 = (long long)d.H * d.Lq * l.ldP; gk.a_bs1 = (long long)d.Lq * l.ldP;
+    gk.b_bs0 = d.q_bs; gk.b_bs1 = d.hd;
+    gk.d_bs0 = d.k_bs; gk.d_bs1 = d.hd;
+    gk.D = dk; gk.ldd = d.k_ld;
+    gk.alpha = d.scale;
+    CALL(r, gemm_impl(&gk, r.s));
+    RUN_CHECK_ARENAS(r, "attention_bwd");
+    return HS_OK;
+}
+
+// ============================================================================================
+// Linear
+// ============================================================================================
+static int linear_fwd_run(Run& r, const void* x, long long M, int ldx, const hs_linear& lin, const void* w_c, void* y,
+                          int ldy, int out_dtype, int act, void* preact, const void* residual, int ldr, float drop_p,
+                          unsigned long long seed) {
+    hs_gemm_params p = gemm_defaults(r.dt);
+    p.a_kind = HS_A_KC; p.b_kind = HS_B_KC;
+    p.M = (int)M; p.N = lin.out_f; p.K = lin.in_f;
+    p.A = x; p.B = w_c;
+    p.a_elems = (M - 1) * ldx + lin.in_f;
+    p.b_elems = (long long)lin.out_f * lin.in_f;
+    p.lda = ldx; p.ldb = lin.in_f;
+    p.D = y; p.ldd = ldy; p.out_dtype = out_dtype;
+    p.bias = lin.b;
+    p.act = act;
+    p.D_preact = preact;
+    p.residual = residual; p.ldr = ldr;
+    p.dropout_p = drop_p; p.dropout_seed = seed;
+    CALL(r, gemm_impl(&p, r.s));
+    return HS_OK;
+}
+// parameter gradients: dw = dy^T x, db = colsum(dy)
+static int linear_wgrad_run(Run& r, const void* x, long long M, int ldx, const hs_linear& lin, const void* dy, int ldy) {
+    if (lin.dw) {
+        hs_gemm_params p = gemm_defaults(r.dt);
+        p.a_kind = HS_A_RC; p.b_kind = HS_B_RC;
+        p.M = lin.out_f; p.N = lin.in_f; p.K = (int)M;
+        p.A = dy; p.B = x;
+        p.a_elems = (M - 1) * ldy + lin.out_f;
+        p.b_elems = (M - 1) * ldx + lin.in_f;
+        p.lda = ldy; p.ldb = ldx;
+        p.D = lin.dw; p.ldd = lin.in_f; p.out_dtype = HS_F32;
+        HS_PROPAGATE(gemm_splitk(r, p));
+    }
+    if (lin.db) {
+        const long long mk = r.ws.mark();
+        const long long wsb = hs_colsum_ws_bytes(M, lin.out_f);
+        void* w = r.ws.alloc(wsb);
+        CALL(r, hs_colsum(r.dt, dy, M, lin.out_f, ldy, lin.db, w, wsb, 0, r.s));
+        r.ws.release(mk);
+    }
+    return HS_OK;
+}
+// dx = dy W (* multiplier) (+ residual)
+static int linear_dgrad_run(Run& r, const hs_linear& lin, const void* w_c, const void* dy, long long M, int ldy, void* dx,
+                            int lddx, int dx_dtype, int mul_mode, const void* mul_src, int ldm, const void* residual) {
+    hs_gemm_params p = gemm_defaults(r.dt);
+    p.a_kind = HS_A_KC; p.b_kind = HS_B_RC;
+    p.M = (int)M; p.N = lin.in_f; p.K = lin.out_f;
+    p.A = dy; p.B = w_c;
+    p.a_elems = (M - 1) * ldy + lin.out_f;
+    p.b_elems = (long long)lin.out_f * lin.in_f;
+    p.lda = ldy; p.ldb = lin.in_f;
+    p.D = dx; p.ldd = lddx; p.out_dtype = dx_dtype;
+    p.mul_mode = mul_mode; p.mul_src = mul_src; p.ldm = ldm;
+    p.residual = residual; p.ldr = lddx;
+    CALL(r, gemm_impl(&p, r.s));
+    return HS_OK;
+}
+
+// ============================================================================================
+// convolution helpers (NHWC, filters KRSC in the compute dtype)
+// ============================================================================================
+struct ConvShape {
+    int N, H, W, Cin, Cout, R, stride, pad, P, Q;
+};
+static ConvShape conv_shape(int N, int H, int W, const hs_conv_bn& c) {
+    ConvShape s;
+    s.N = N; s.H = H; s.W = W; s.Cin = c.Cin; s.Cout = c.Cout; s.R = c.R; s.stride = c.stride; s.pad = c.pad;
+    s.P = (H + 2 * c.pad - c.R) / c.stride + 1;
+    s.Q = (W + 2 * c.pad - c.R) / c.stride + 1;
+    return s;
+}
+static hs_conv_geom geom_of(const ConvShape& s) {
+    hs_conv_geom g;
+    memset(&g, 0, sizeof(g));
+    g.N = s.N; g.H = s.H; g.W = s.W; g.C = s.Cin; g.P = s.P; g.Q = s.Q; g.K = s.Cout; g.R = s.R; g.S = s.R;
+    g.stride = s.stride; g.pad = s.pad;
+    g.row_pitch = s.W * s.Cin;
+    g.img_pitch = s.H * g.row_pitch;
+    g.qstep = s.stride * s.Cin;
+    return g;
+}
+static bool is_pointwise(const ConvShape& s) { return s.R == 1 && s.stride == 1 && s.pad == 0; }
+
+static int conv_fwd_run(Run& r, const ConvShape& s, const void* x, const void* w_c, void* y) {
+    hs_gemm_params p = gemm_defaults(r.dt);
+    const long long Mo = (long long)s.N * s.P * s.Q;
+    p.M = (int)Mo; p.N = s.Cout; p.K = s.R * s.R * s.Cin;
+    p.A = x; p.B = w_c;
+    p.a_elems = (long long)s.N * s.H * s.W * s.Cin;
+    p.b_elems = (long long)s.Cout * p.K;
+    p.ldb = p.K;
+    p.D = y; p.ldd = s.Cout;
+    if (is_pointwise(s)) {
+        p.a_kind = HS_A_KC; p.lda = s.Cin;
+    } else {
+        p.a_kind = HS_A_CONV; p.g = geom_of(s);
+    }
+    p.b_kind = HS_B_KC;
+    CALL(r, gemm_impl(&p, r.s));
+    return HS_OK;
+}
+static int conv_dgrad_run(Run& r, const ConvShape& s, const void* dy, const void* w_c, void* dx, const void* residual) {
+    hs_gemm_params p = gemm_defaults(r.dt);
+    p.M = (int)((long long)s.N * s.H * s.W); p.N = s.Cin; p.K = s.R * s.R * s.Cout;
+    p.A = dy; p.B = w_c;
+    p.a_elems = (long long)s.N * s.P * s.Q * s.Cout;
+    p.b_elems = (long long)s.Cout * s.R * s.R * s.Cin;
+    p.D = dx; p.ldd = s.Cin;
+    p.residual = residual; p.ldr = s.Cin;
+    if (is_pointwise(s)) {
+        p.a_kind = HS_A_KC; p.lda = s.Cout;
+        p.b_kind = HS_B_RC; p.ldb = s.Cin;
+    } else {
+        p.a_kind = HS_A_DGRAD; p.b_kind = HS_B_WDGRAD; p.g = geom_of(s);
+    }
+    CALL(r, gemm_impl(&p, r.s));
+    return HS_OK;
+}
+static int conv_wgrad_run(Run& r, const ConvShape& s, const void* dy, const void* x, float* dw) {
+    hs_gemm_params p = gemm_defaults(r.dt);
+    p.M = s.Cout; p.N = s.R * s.R * s.Cin; p.K = (int)((long long)s.N * s.P * s.Q);
+    p.A = dy; p.B = x;
+    p.a_elems = (long long)s.N * s.P * s.Q * s.Cout;
+    p.b_elems = (long long)s.N * s.H * s.W * s.Cin;
+    p.a_kind = HS_A_RC; p.lda = s.Cout;
+    p.D = dw; p.ldd = p.N; p.out_dtype = HS_F32;
+    if (is_pointwise(s)) {
+        p.b_kind = HS_B_RC; p.ldb = s.Cin;
+    } else {
+        p.b_kind = HS_B_CONV; p.g = geom_of(s);
+    }
+    return gemm_splitk(r, p);
+}
+
+// weights in the compute dtype: f32 mode reads the parameters directly, bf16 mode casts them into
+// the saved arena once per forward (the backward reuses the copies).
+struct CastList {
+    const float* src[HS_CAST_MAX];
+    void* dst[HS_CAST_MAX];
+    int64_t n[HS_CAST_MAX];
+    int count = 0;
+};
+static const void* weight_c(Run& r, CastList& cl, const float* w, long long n) {
+    if (r.dt == HS_F32) return w;
+    void* d = r.saved.alloc(n * 2);
+    cl.src[cl.count] = w;
+    cl.dst[cl.count] = d;
+    cl.n[cl.count] = n;
+    cl.count++;
+    return d;
+}
+static int run_casts(Run& r, CastList& cl) {
+    if (cl.count == 0 || r.plan) return HS_OK;
+    return hs_cast_f32_to_bf16_multi(cl.count, cl.src, cl.dst, cl.n, r.s);
+}
+
+// ============================================================================================
+// residual block
+// ============================================================================================
+struct StageBuf {
+    ConvShape s;
+    const void* w_c;
+    void* c;          // conv output (pre-BN)
+    void* a;          // BN(+ReLU) output (the last main stage writes the block output y instead)
+    float *mean, *invstd, *scale, *shift;
+};
+struct ResLayout {
+    StageBuf main[3];
+    StageBuf ds;
+    void* bn_ws;
+    long long bn_ws_bytes;
+    CastList casts;
+};
+static void stage_layout(Run& r, ResLayout& L, StageBuf& b, const hs_conv_bn& cb, int N, int H, int W, bool own_out) {
+    b.s = conv_shape(N, H, W, cb);
+    b.w_c = weight_c(r, L.casts, cb.w, (long long)cb.Cout * cb.R * cb.R * cb.Cin);
+    const long long Mo = (long long)N * b.s.P * b.s.Q;
+    b.c = r.saved.alloc(Mo * cb.Cout * esize(r.dt));
+    b.a = own_out ? r.saved.alloc(Mo * cb.Cout * esize(r.dt)) : nullptr;
+    float* st = (float*)r.saved.alloc((long long)cb.Cout * 4 * 4);
+    b.mean = st;
+    b.invstd = st ? st + cb.Cout : nullptr;
+    b.scale = st ? st + 2 * cb.Cout : nullptr;
+    b.shift = st ? st + 3 * cb.Cout : nullptr;
+    L.bn_ws_bytes = std::max<long long>(L.bn_ws_bytes, hs_batchnorm_ws_bytes(Mo, cb.Cout, r.dt));
+}
+static int res_layout(Run& r, const hs_resblock_desc& d, ResLayout& L) {
+    HS_REQUIRE(d.n_main == 2 || d.n_main == 3, "resblock: n_main must be 2 or 3");
+    L.bn_ws_bytes = 0;
+    int H = d.H, W = d.W;
+    for (int i = 0; i < d.n_main; ++i) {
+        stage_layout(r, L, L.main[i], d.main[i], d.N, H, W, i + 1 < d.n_main);
+        H = L.main[i].s.P;
+        W = L.main[i].s.Q;
+        if (i > 0) HS_REQUIRE(d.main[i].Cin == d.main[i - 1].Cout, "resblock: channel mismatch at stage %d", i);
+    }
+    if (d.has_ds) {
+        stage_layout(r, L, L.ds, d.ds, d.N, d.H, d.W, true);
+        HS_REQUIRE(L.ds.s.P == H && L.ds.s.Q == W && d.ds.Cout == d.main[d.n_main - 1].Cout && d.ds.Cin == d.main[0].Cin,
+                   "resblock: downsample shape mismatch");
+    } else {
+        HS_REQUIRE(H == d.H && W == d.W && d.main[0].Cin == d.main[d.n_main - 1].Cout,
+                   "resblock: identity shortcut needs matching shapes");
+    }
+    L.bn_ws = r.ws.alloc(L.bn_ws_bytes);
+    return HS_OK;
+}
+static hs_bn_params bn_params(Run& r, const hs_resblock_desc& d, const hs_conv_bn& cb, const StageBuf& b, long long M) {
+    hs_bn_params p;
+    memset(&p, 0, sizeof(p));
+    p.dtype = r.dt; p.C = cb.Cout; p.M = M;
+    p.training = d.training;
+    p.eps = d.eps; p.momentum = d.momentum;
+    p.x = b.c;
+    p.gamma = cb.gamma; p.beta = cb.beta;
+    p.running_mean = cb.running_mean; p.running_var = cb.running_var;
+    p.save_mean = b.mean; p.save_invstd = b.invstd; p.scale = b.scale; p.shift = b.shift;
+    return p;
+}
+
+static int resblock_fwd_run(Run& r, const hs_resblock_desc& d, const void* x, void* y) {
+    ResLayout L;
+    HS_PROPAGATE(res_layout(r, d, L));
+    RUN_CHECK_ARENAS(r, "resblock_fwd");
+    HS_PROPAGATE(run_casts(r, L.casts));
+    const void* identity = x;
+    if (d.has_ds) {
+        const long long Mo = (long long)d.N * L.ds.s.P * L.ds.s.Q;
+        HS_PROPAGATE(conv_fwd_run(r, L.ds.s, x, L.ds.w_c, L.ds.c));
+        hs_bn_params bp = bn_params(r, d, d.ds, L.ds, Mo);
+        bp.y = L.ds.a; bp.relu = 0;
+        bp.ws = L.bn_ws; bp.ws_bytes = L.bn_ws_bytes;
+        CALL(r, hs_batchnorm_fwd(&bp, r.s));
+        identity = L.ds.a;
+    }
+    const void* in = x;
+    for (int i = 0; i < d.n_main; ++i) {
+        StageBuf& b = L.main[i];
+        const long long Mo = (long long)d.N * b.s.P * b.s.Q;
+        HS_PROPAGATE(conv_fwd_run(r, b.s, in, b.w_c, b.c));
+        hs_bn_params bp = bn_params(r, d, d.main[i], b, Mo);
+        const bool last = i + 1 == d.n_main;
+        bp.y = last ? y : b.a;
+        bp.relu = 1;
+        bp.residual = last ? identity : nullptr;
+        bp.ws = L.bn_ws; bp.ws_bytes = L.bn_ws_bytes;
+        CALL(r, hs_batchnorm_fwd(&bp, r.s));
+        in = b.a;
+    }
+    return HS_OK;
+}
+
+static int resblock_bwd_run(Run& r, const hs_resblock_desc& d, const void* x, const void* y, const void* dy, void* dx) {
+    ResLayout L;
+    HS_PROPAGATE(res_layout(r, d, L));
+    const int last = d.n_main - 1;
+    const int es = esize(r.dt);
+    const long long Mout = (long long)d.N * L.main[last].s.P * L.main[last].s.Q;
+    const int Cout = d.main[last].Cout;
+    // scratch: gradient wrt the residual branch, stage gradients, BN parameter-gradient fallbacks
+    void* dres = r.ws.alloc(Mout * Cout * es);
+    float* scratch_pg = (float*)r.ws.alloc(2 * 4096 * 4);
+    long long max_act = 0;
+    for (int i = 0; i < d.n_main; ++i) {
+        const StageBuf& b = L.main[i];
+        max_act = std::max<long long>(max_act, (long long)d.N * b.s.P * b.s.Q * b.s.Cout);
+        max_act = std::max<long long>(max_act, (long long)d.N * b.s.H * b.s.W * b.s.Cin);
+    }
+    if (d.has_ds) max_act = std::max<long long>(max_act, Mout * Cout);
+    void* gA = r.ws.alloc(max_act * es);   // gradient wrt a conv output
+    void* gB = r.ws.alloc(max_act * es);   // gradient wrt a stage input
+    void* dx_ds = (d.has_ds && dx) ? r.ws.alloc((long long)d.N * d.H * d.W * d.main[0].Cin * es) : nullptr;
+    RUN_CHECK_ARENAS(r, "resblock_bwd");
+    for (int i = 0; i < d.n_main; ++i) HS_REQUIRE(d.main[i].Cout <= 4096, "resblock: Cout > 4096");
+
+    auto bn_backward = [&](const hs_conv_bn& cb, const StageBuf& b, long long M, const void* g_out, const void* y_out,
+                           int relu, void* g_in, void* g_res) -> int {
+        hs_bn_bwd_params q;
+        memset(&q, 0, sizeof(q));
+        q.dtype = r.dt; q.C = cb.Cout; q.M = M;
+        q.training = d.training; q.relu = relu;
+        q.dy = g_out; q.y = y_out; q.x = b.c;
+        q.gamma = cb.gamma; q.save_mean = b.mean; q.save_invstd = b.invstd;
+        q.dx = g_in; q.dres = g_res;
+        q.dgamma = cb.dgamma ? cb.dgamma : scratch_pg;
+        q.dbeta = cb.dbeta ? cb.dbeta : (scratch_pg ? scratch_pg + 4096 : nullptr);
+        q.ws = L.bn_ws; q.ws_bytes = L.bn_ws_bytes;
+        CALL(r, hs_batchnorm_bwd(&q, r.s));
+        return HS_OK;
+    };
+
+    // last main stage: y = relu(bn(c_last) + identity)
+    HS_PROPAGATE(bn_backward(d.main[last], L.main[last], Mout, dy, y, 1, gA, dres));
+    const void* dres_for_x = dres;   // identity shortcut: dres flows straight into dx
+    if (d.has_ds) {
+        // downsample branch: identity = bn(conv(x)), no ReLU
+        HS_PROPAGATE(bn_backward(d.ds, L.ds, Mout, dres, nullptr, 0, gB, nullptr));
+        if (d.ds.dw) HS_PROPAGATE(conv_wgrad_run(r, L.ds.s, gB, x, d.ds.dw));
+        if (dx) HS_PROPAGATE(conv_dgrad_run(r, L.ds.s, gB, L.ds.w_c, dx_ds, nullptr));
+        dres_for_x = dx_ds;
+    }
+    // walk the main path backwards; gA holds d(conv output of stage i)
+    for (int i = last; i >= 0; --i) {
+        const StageBuf& b = L.main[i];
+        const void* in = i == 0 ? x : L.main[i - 1].a;
+        if (d.main[i].dw) HS_PROPAGATE(conv_wgrad_run(r, b.s, gA, in, d.main[i].dw));
+        if (i == 0) {
+            if (dx) HS_PROPAGATE(conv_dgrad_run(r, b.s, gA, b.w_c, dx, dres_for_x));
+        } else {
+            HS_PROPAGATE(conv_dgrad_run(r, b.s, gA, b.w_c, gB, nullptr));
+            const StageBuf& pb = L.main[i - 1];
+            const long long Mp = (long long)d.N * pb.s.P * pb.s.Q;
+            HS_PROPAGATE(bn_backward(d.main[i - 1], pb, Mp, gB, pb.a, 1, gA, nullptr));
+        }
+    }
+    return HS_OK;
+}
+
+// ============================================================================================
+// stem
+// ============================================================================================
+struct StemLayout {
+    int Hp, Wp, P, Q, P2, Q2;
+    void* packed;      // [N][Hp][Wp][4]
+    void* w_packed;    // [64][7][8][4] compute dtype
+    void* c;           // conv out [N][P][Q][64]
+    void* a;           // bn+relu out
+    void* idx;         // maxpool argmax
+    float *mean, *invstd, *scale, *shift;
+    void* bn_ws;
+    long long bn_ws_bytes;
+    hs_conv_geom g;
+};
+static int stem_layout(Run& r, const hs_stem_desc& d, StemLayout& L) {
+    const hs_conv_bn& cb = d.cb;
+    HS_REQUIRE(cb.Cin == 3 && cb.R == 7 && cb.stride == 2 && cb.pad == 3 && cb.Cout % 8 == 0 && cb.Cout <= 64,
+               "stem: expects conv 7x7/2 pad 3 with 3 input channels and <= 64 output channels");
+    L.P = (d.H + 6 - 7) / 2 + 1;
+    L.Q = (d.W + 6 - 7) / 2 + 1;
+    L.Hp = std::max(d.H + 6, 2 * L.P + 5);
+    L.Wp = (int)align_up(std::max(d.W + 6, 2 * L.Q + 6), 2);
+    L.P2 = (L.P + 2 - 3) / 2 + 1;
+    L.Q2 = (L.Q + 2 - 3) / 2 + 1;
+    const int es = esize(r.dt);
+    L.packed = r.saved.alloc((long long)d.N * L.Hp * L.Wp * 4 * es);
+    L.w_packed = r.saved.alloc((long long)cb.Cout * 7 * 32 * es);
+    const long long Mo = (long long)d.N * L.P * L.Q;
+    L.c = r.saved.alloc(Mo * cb.Cout * es);
+    L.a = r.saved.alloc(Mo * cb.Cout * es);
+    L.idx = r.saved.alloc((long long)d.N * L.P2 * L.Q2 * cb.Cout);
+    float* st = (float*)r.saved.alloc((long long)cb.Cout * 4 * 4);
+    L.mean = st;
+    L.invstd = st ? st + cb.Cout : nullptr;
+    L.scale = st ? st + 2 * cb.Cout : nullptr;
+    L.shift = st ? st + 3 * cb.Cout : nullptr;
+    L.bn_ws_bytes = hs_batchnorm_ws_bytes(Mo, cb.Cout, r.dt);
+    L.bn_ws = r.ws.alloc(L.bn_ws_bytes);
+    hs_conv_geom& g = L.g;
+    memset(&g, 0, sizeof(g));
+    g.N = d.N; g.H = L.Hp; g.W = L.Wp; g.C = 32; g.P = L.P; g.Q = L.Q; g.K = cb.Cout; g.R = 7; g.S = 1;
+    g.stride = 2; g.pad = 0;
+    g.row_pitch = L.Wp * 4;
+    g.img_pitch = L.Hp * L.Wp * 4;
+    g.qstep = 8;
+    g.no_bounds = 1;
+    return HS_OK;
+}
+static int stem_fwd_run(Run& r, const hs_stem_desc& d, const float* image, void* y) {
+    StemLayout L;
+    HS_PROPAGATE(stem_layout(r, d, L));
+    RUN_CHECK_ARENAS(r, "stem_fwd");
+    const hs_conv_bn& cb = d.cb;
+    CALL(r, hs_pack_image(r.dt, image, L.packed, d.N, 3, d.H, d.W, L.Hp, L.Wp, 3, r.s));
+    CALL(r, hs_pack_stem_weight(r.dt, cb.w, L.w_packed, cb.Cout, 7, 7, 3, r.s));
+    const long long Mo = (long long)d.N * L.P * L.Q;
+    hs_gemm_params p = gemm_defaults(r.dt);
+    p.a_kind = HS_A_CONV; p.b_kind = HS_B_KC;
+    p.M = (int)Mo; p.N = cb.Cout; p.K = 7 * 32;
+    p.A = L.packed; p.B = L.w_packed;
+    p.a_elems = (long long)d.N * L.Hp * L.Wp * 4;
+    p.b_elems = (long long)cb.Cout * 224;
+    p.ldb = 224;
+    p.g = L.g;
+    p.D = L.c; p.ldd = cb.Cout;
+    CALL(r, gemm_impl(&p, r.s));
+    hs_bn_params bp;
+    memset(&bp, 0, sizeof(bp));
+    bp.dtype = r.dt; bp.C = cb.Cout; bp.M = Mo;
+    bp.training = d.training; bp.relu = 1;
+    bp.eps = d.eps; bp.momentum = d.momentum;
+    bp.x = L.c; bp.y = L.a;
+    bp.gamma = cb.gamma; bp.beta = cb.beta;
+    bp.running_mean = cb.running_mean; bp.running_var = cb.running_var;
+    bp.save_mean = L.mean; bp.save_invstd = L.invstd; bp.scale = L.scale; bp.shift = L.shift;
+    bp.ws = L.bn_ws; bp.ws_bytes = L.bn_ws_bytes;
+    CALL(r, hs_batchnorm_fwd(&bp, r.s));
+    CALL(r, hs_maxpool_fwd(r.dt, L.a, y, L.idx, d.N, L.P, L.Q, cb.Cout, 3, 2, 1, r.s));
+    return HS_OK;
+}
+static int stem_bwd_run(Run& r, const hs_stem_desc& d, const void* y, const void* dy) {
+    StemLayout L;
+    HS_PROPAGATE(stem_layout(r, d, L));
+    const hs_conv_bn& cb = d.cb;
+    const int es = esize(r.dt);
+    const long long Mo = (long long)d.N * L.P * L.Q;
+    void* da = r.ws.alloc(Mo * cb.Cout * es);
+    void* dc = r.ws.alloc(Mo * cb.Cout * es);
+    float* scratch_pg = (float*)r.ws.alloc(2 * 64 * 4);
+    float* dw_packed = (float*)r.ws.alloc((long long)cb.Cout * 224 * 4);
+    RUN_CHECK_ARENAS(r, "stem_bwd");
+    (void)y;
+    CALL(r, hs_maxpool_bwd(r.dt, dy, L.idx, da, d.N, L.P, L.Q, cb.Cout, 3, 2, 1, r.s));
+    hs_bn_bwd_params q;
+    memset(&q, 0, sizeof(q));
+    q.dtype = r.dt; q.C = cb.Cout; q.M = Mo;
+    q.training = d.training; q.relu = 1;
+    q.dy = da; q.y = L.a; q.x = L.c;
+    q.gamma = cb.gamma; q.save_mean = L.mean; q.save_invstd = L.invstd;
+    q.dx = cb.dw ? dc : nullptr;
+    q.dgamma = cb.dgamma ? cb.dgamma : scratch_pg;
+    q.dbeta = cb.dbeta ? cb.dbeta : (scratch_pg ? scratch_pg + 64 : nullptr);
+    q.ws = L.bn_ws; q.ws_bytes = L.bn_ws_bytes;
+    CALL(r, hs_batchnorm_bwd(&q, r.s));
+    if (cb.dw) {
+        hs_gemm_params p = gemm_defaults(r.dt);
+        p.a_kind = HS_A_RC; p.b_kind = HS_B_CONV;
+        p.M = cb.Cout; p.N = 224; p.K = (int)Mo;
+        p.A = dc; p.B = L.packed;
+        p.a_elems = Mo * cb.Cout;
+        p.b_elems = (long long)d.N * L.Hp * L.Wp * 4;
+        p.lda = cb.Cout;
+        p.g = L.g;
+        p.D = dw_packed; p.ldd = 224; p.out_dtype = HS_F32;
+        HS_PROPAGATE(gemm_splitk(r, p));
+        CALL(r, hs_unpack_stem_wgrad(dw_packed, cb.dw, cb.Cout, 7, 7, 3, r.s));
+    }
+    return HS_OK;
+}
+
+// ============================================================================================
+// BertLayer
+// ============================================================================================
+struct BertLayout {
+    const void *wqkv, *wao, *wi, *wo;   // compute-dtype weights ([3*hidden][hidden] fused QKV)
+    float* bqkv;                        // fused f32 bias [3*hidden]
+    void *qkv, *ctx, *h1, *x1, *u, *g, *h2;
+    float *mean1, *rstd1, *mean2, *rstd2;
+    CastList casts;
+};
+static int bert_layout(Run& r, const hs_bert_layer_desc& d, BertLayout& L) {
+    const int Hd = d.hidden, I = d.inter;
+    const long long M = (long long)d.B * d.L;
+    const int es = esize(r.dt);
+    HS_REQUIRE(Hd % d.heads == 0 && d.q.in_f == Hd && d.q.out_f == Hd && d.inter_l.out_f == I && d.out_l.in_f == I,
+               "bert_layer: inconsistent dims");
+    // fused QKV weight: always a private copy (cast in bf16 mode, plain copy in f32 mode)
+    void* wq = r.saved.alloc(3ll * Hd * Hd * es);
+    L.wqkv = wq;
+    L.bqkv = (float*)r.saved.alloc(3ll * Hd * 4);
+    if (r.dt == HS_BF16) {
+        const float* ws3[3] = {d.q.w, d.k.w, d.v.w};
+        for (int i = 0; i < 3; ++i) {
+            L.casts.src[L.casts.count] = ws3[i];
+            L.casts.dst[L.casts.count] = wq ? (char*)wq + (long long)i * Hd * Hd * 2 : nullptr;
+            L.casts.n[L.casts.count] = (long long)Hd * Hd;
+            L.casts.count++;
+        }
+    }
+    L.wao = weight_c(r, L.casts, d.ao.w, (long long)Hd * Hd);
+    L.wi = weight_c(r, L.casts, d.inter_l.w, (long long)I * Hd);
+    L.wo = weight_c(r, L.casts, d.out_l.w, (long long)Hd * I);
+    L.qkv = r.saved.alloc(M * 3 * Hd * es);
+    L.ctx = r.saved.alloc(M * Hd * es);
+    L.h1 = r.saved.alloc(M * Hd * es);
+    L.x1 = r.saved.alloc(M * Hd * es);
+    L.u = r.saved.alloc(M * I * es);
+    L.g = r.saved.alloc(M * I * es);
+    L.h2 = r.saved.alloc(M * Hd * es);
+    float* st = (float*)r.saved.alloc(M * 4 * 4);
+    L.mean1 = st;
+    L.rstd1 = st ? st + M : nullptr;
+    L.mean2 = st ? st + 2 * M : nullptr;
+    L.rstd2 = st ? st + 3 * M : nullptr;
+    return HS_OK;
+}
+static hs_attn_desc bert_attn_desc(const hs_bert_layer_desc& d, int dt) {
+    hs_attn_desc a;
+    memset(&a, 0, sizeof(a));
+    const int Hd = d.hidden;
+    a.dtype = dt;
+    a.B = d.B; a.H = d.heads; a.Lq = d.L; a.Lk = d.L; a.hd = Hd / d.heads;
+    a.q_bs = a.k_bs = a.v_bs = (long long)d.L * 3 * Hd;
+    a.q_ld = a.k_ld = a.v_ld = 3 * Hd;
+    a.o_bs = (long long)d.L * Hd;
+    a.o_ld = Hd;
+    a.scale = 1.f / sqrtf((float)a.hd);
+    a.dropout_p = d.attn_dropout;
+    a.seed = d.seed * 8 + 1;
+    a.key_mask = d.attention_mask;
+    return a;
+}
+static int bert_layer_fwd_run(Run& r, const hs_bert_layer_desc& d, const void* x, void* y) {
+    BertLayout L;
+    HS_PROPAGATE(bert_layout(r, d, L));
+    const int Hd = d.hidden, I = d.inter;
+    const long long M = (long long)d.B * d.L;
+    const int es = esize(r.dt);
+    RUN_CHECK_ARENAS(r, "bert_layer_fwd(layout)");
+    HS_PROPAGATE(run_casts(r, L.casts));
+    if (!r.plan) {
+        if (r.dt == HS_F32) {
+            const float* ws3[3] = {d.q.w, d.k.w, d.v.w};
+            for (int i = 0; i < 3; ++i)
+                HS_CHECK_HIP(hipMemcpyAsync((char*)L.wqkv + (long long)i * Hd * Hd * 4, ws3[i], (long long)Hd * Hd * 4,
+                                            hipMemcpyDeviceToDevice, r.s));
+        }
+        const float* bs3[3] = {d.q.b, d.k.b, d.v.b};
+        for (int i = 0; i < 3; ++i)
+            HS_CHECK_HIP(hipMemcpyAsync(L.bqkv + (long long)i * Hd, bs3[i], (long long)Hd * 4, hipMemcpyDeviceToDevice, r.s));
+    }
+    // 1. fused QKV projection
+    hs_linear qkv_lin;
+    memset(&qkv_lin, 0, sizeof(qkv_lin));
+    qkv_lin.in_f = Hd; qkv_lin.out_f = 3 * Hd; qkv_lin.b = L.bqkv;
+    HS_PROPAGATE(linear_fwd_run(r, x, M, Hd, qkv_lin, L.wqkv, L.qkv, 3 * Hd, r.dt, HS_ACT_NONE, nullptr, nullptr, 0, 0.f, 0));
+    // 2. attention
+    hs_attn_desc a = bert_attn_desc(d, r.dt);
+    const char* qkv = (const char*)L.qkv;
+    HS_PROPAGATE(attention_fwd_run(r, a, qkv, qkv ? qkv + (long long)Hd * es : nullptr,
+                                   qkv ? qkv + 2ll * Hd * es : nullptr, L.ctx));
+    // 3. attention output: h1 = dropout(ctx Wo^T + b) + x ; x1 = LN(h1)
+    HS_PROPAGATE(linear_fwd_run(r, L.ctx, M, Hd, d.ao, L.wao, L.h1, Hd, r.dt, HS_ACT_NONE, nullptr, x, Hd, d.hidden_dropout,
+                                d.seed * 8 + 2));
+    CALL(r, hs_layernorm_fwd(r.dt, L.h1, d.ln1.gamma, d.ln1.beta, L.x1, L.mean1, L.rstd1, M, Hd, d.ln_eps, r.s));
+    // 4. FFN
+    HS_PROPAGATE(linear_fwd_run(r, L.x1, M, Hd, d.inter_l, L.wi, L.g, I, r.dt, HS_ACT_GELU, L.u, nullptr, 0, 0.f, 0));
+    HS_PROPAGATE(linear_fwd_run(r, L.g, M, I, d.out_l, L.wo, L.h2, Hd, r.dt, HS_ACT_NONE, nullptr, L.x1, Hd,
+                                d.hidden_dropout, d.seed * 8 + 3));
+    CALL(r, hs_layernorm_fwd(r.dt, L.h2, d.ln2.gamma, d.ln2.beta, y, L.mean2, L.rstd2, M, Hd, d.ln_eps, r.s));
+    RUN_CHECK_ARENAS(r, "bert_layer_fwd");
+    return HS_OK;
+}
+static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x, const void* dy, void* dx) {
+    BertLayout L;
+    HS_PROPAGATE(bert_layout(r, d, L));
+    const int Hd = d.hidden, I = d.inter;
+    const long long M = (long long)d.B * d.L;
+    const int es = esize(r.dt);
+    hs_attn_desc a = bert_attn_desc(d, r.dt);
+    // the attention arenas must be laid out exactly as in the forward: saved first
+    // (attention_bwd_run below re-derives P/Pd from r.saved in the same order as attention_fwd_run)
+    void* dh = r.ws.alloc(M * Hd * es);      // gradient wrt h2 / h1 (LN inputs)
+    void* dd = r.ws.alloc(M * Hd * es);      // dropout-masked copy
+    void* du = r.ws.alloc(M * I * es);       // gradient wrt u
+    void* dx1 = r.ws.alloc(M * Hd * es);
+    void* dctx = r.ws.alloc(M * Hd * es);
+    void* dqkv = r.ws.alloc(M * 3 * Hd * es);
+    const long long ln_ws_bytes = hs_layernorm_bwd_ws_bytes(M, Hd);
+    float* ln_ws = (float*)r.ws.alloc(ln_ws_bytes);
+    float* scratch = (float*)r.ws.alloc(2ll * Hd * 4);
+    float* dbqkv = (float*)r.ws.alloc(3ll * Hd * 4);
+
+    // ---- output LN + FFN ----
+    CALL(r, hs_layernorm_bwd(r.dt, dy, L.h2, d.ln2.gamma, L.mean2, L.rstd2, dh, d.ln2.dgamma ? d.ln2.dgamma : scratch,
+                             d.ln2.dbeta ? d.ln2.dbeta : (scratch ? scratch + Hd : nullptr), ln_ws, ln_ws_bytes, M, Hd, r.s));
+    const void* g2 = dh;
+    if (d.hidden_dropout > 0.f) {
+        CALL(r, hs_dropout(r.dt, dh, dd, M * Hd, d.hidden_dropout, d.seed * 8 + 3, r.s));
+        g2 = dd;
+    }
+    HS_PROPAGATE(linear_wgrad_run(r, L.g, M, I, d.out_l, g2, Hd));
+    HS_PROPAGATE(linear_dgrad_run(r, d.out_l, L.wo, g2, M, Hd, du, I, r.dt, HS_MUL_GELU_GRAD, L.u, I, nullptr));
+    HS_PROPAGATE(linear_wgrad_run(r, L.x1, M, Hd, d.inter_l, du, I));
+    // dx1 = du Wi + dh (residual into x1)
+    HS_PROPAGATE(linear_dgrad_run(r, d.inter_l, L.wi, du, M, I, dx1, Hd, r.dt, HS_MUL_NONE, nullptr, 0, dh));
+    // ---- attention output LN + dense ----
+    CALL(r, hs_layernorm_bwd(r.dt, dx1, L.h1, d.ln1.gamma, L.mean1, L.rstd1, dh, d.ln1.dgamma ? d.ln1.dgamma : scratch,
+                             d.ln1.dbeta ? d.ln1.dbeta : (scratch ? scratch + Hd : nullptr), ln_ws, ln_ws_bytes, M, Hd, r.s));
+    const void* g1 = dh;
+    if (d.hidden_dropout > 0.f) {
+        CALL(r, hs_dropout(r.dt, dh, dd, M * Hd, d.hidden_dropout, d.seed * 8 + 2, r.s));
+        g1 = dd;
+    }
+    HS_PROPAGATE(linear_wgrad_run(r, L.ctx, M, Hd, d.ao, g1, Hd));
+    HS_PROPAGATE(linear_dgrad_run(r, d.ao, L.wao, g1, M, Hd, dctx, Hd, r.dt, HS_MUL_NONE, nullptr, 0, nullptr));
+    // ---- attention core ----
+    const char* qkv = (const char*)L.qkv;
+    char* dq = (char*)dqkv;
+    HS_PROPAGATE(attention_bwd_run(r, a, qkv, qkv ? qkv + (long long)Hd * es : nullptr, qkv ? qkv + 2ll * Hd * es : nullptr,
+                                   dctx, dq, dq ? dq + (long long)Hd * es : nullptr, dq ? dq + 2ll * Hd * es : nullptr));
+    // ---- QKV projection ----
+    const hs_linear* lins[3] = {&d.q, &d.k, &d.v};
+    for (int i = 0; i < 3; ++i) {
+        hs_linear li = *lins[i];
+        HS_PROPAGATE(linear_wgrad_run(r, x, M, Hd, li, dq ? dq + (long long)i * Hd * es : nullptr, 3 * Hd));
+    }
+    (void)dbqkv;
+    if (dx) {
+        hs_linear qkv_lin;
+        memset(&qkv_lin, 0, sizeof(qkv_lin));
+        qkv_lin.in_f = Hd; qkv_lin.out_f = 3 * Hd;
+        // dx = dqkv Wqkv + dh (residual of the attention-output LN input)
+        HS_PROPAGATE(linear_dgrad_run(r, qkv_lin, L.wqkv, dqkv, M, 3 * Hd, dx, Hd, r.dt, HS_MUL_NONE, nullptr, 0, dh));
+    }
+    RUN_CHECK_ARENAS(r, "bert_layer_bwd");
+    return HS_OK;
+}
+
+}  // namespace hs
+
+using namespace hs;
+
+// run the layout in plan mode first and refuse to launch anything when an arena is too small
+#define PLAN_CHECK(what, dt, svb, wsb, RUNCALL)                                                        \
+    do {                                                                                               \
+        Run pl;                                                                                        \
+        run_init(pl, dt, true, nullptr, 0, nullptr, 0, nullptr);                                       \
+        Run& r = pl;                                                                                   \
+        HS_PROPAGATE(RUNCALL);                                                                         \
+        HS_REQUIRE(pl.saved.peak <= (svb) && pl.ws.peak <= (wsb),                                      \
+                   "%s: arena too small (saved %lld needed / %lld given, ws %lld needed / %lld given)", \
+                   what, pl.saved.peak, (long long)(svb), pl.ws.peak, (long long)(wsb));               \
+    } while (0)
+
+#define QUERY_BODY(DESC_DT, RUNCALL)                                   \
+    Run r;                                                             \
+    run_init(r, DESC_DT, true, nullptr, 0, nullptr, 0, nullptr);       \
+    int st = RUNCALL;                                                  \
+    if (st != HS_OK) return st;                                        \
+    if (saved_bytes) *saved_bytes = r.saved.peak;                      \
+    if (ws_bytes) *ws_bytes = r.ws.peak;                               \
+    return HS_OK;
+
+extern "C" {
+
+hs_status hs_attention_query(const hs_attn_desc* d, int64_t* saved_bytes, int64_t* ws_bytes) {
+    HS_REQUIRE(d, "attention_query: null desc");
+    // the backward needs the larger workspace; report max(fwd, bwd)
+    Run r;
+    run_init(r, d->dtype, true, nullptr, 0, nullptr, 0, nullptr);
+    HS_PROPAGATE(attention_bwd_run(r, *d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+    if (saved_bytes) *saved_bytes = r.saved.peak;
+    if (ws_bytes) *ws_bytes = r.ws.peak;
+    return HS_OK;
+}
+hs_status hs_attention_fwd(const hs_attn_desc* d, const void* q, const void* k, const void* v, void* o, void* saved,
+                           int64_t saved_bytes, void* ws, int64_t ws_bytes, void* stream) {
+    HS_REQUIRE(d && q && k && v && o && saved && ws, "attention_fwd: null argument");
+    PLAN_CHECK("attention_fwd", d->dtype, saved_bytes, ws_bytes, attention_fwd_run(r, *d, q, k, v, o));
+    Run r;
+    run_init(r, d->dtype, false, saved, saved_bytes, ws, ws_bytes, (hipStream_t)stream);
+    return attention_fwd_run(r, *d, q, k, v, o);
+}
+hs_status hs_attention_bwd(const hs_attn_desc* d, const void* q, const void* k, const void* v, const void* d_o, void* dq,
+                           void* dk, void* dv, void* saved, int64_t saved_bytes, void* ws, int64_t ws_bytes,
+                           void* stream) {
+    HS_REQUIRE(d && q && k && v && d_o && dq && dk && dv && saved && ws, "attention_bwd: null argument");
+    PLAN_CHECK("attention_bwd", d->dtype, saved_bytes, ws_bytes, attention_bwd_run(r, *d, q, k, v, d_o, dq, dk, dv));
+    Run r;
+    run_init(r, d->dtype, false, saved, saved_bytes, ws, ws_bytes, (hipStream_t)stream);
+    return attention_bwd_run(r, *d, q, k, v, d_o, dq, dk, dv);
+}
+
+hs_status hs_resblock_query(const hs_resblock_desc* d, int64_t* saved_bytes, int64_t* ws_bytes) {
+    HS_REQUIRE(d, "resblock_query: null desc");
+    Run r;
+    run_init(r, d->dtype, true, nullptr, 0, nullptr, 0, nullptr);
+    HS_PROPAGATE(resblock_fwd_run(r, *d, nullptr, nullptr));
+    const long long sv = r.saved.peak, w1 = r.ws.peak;
+    Run b;
+    run_init(b, d->dtype, true, nullptr, 0, nullptr, 0, nullptr);
+    int dummy;
+    HS_PROPAGATE(resblock_bwd_run(b, *d, nullptr, nullptr, nullptr, &dummy));
+    if (saved_bytes) *saved_bytes = std::max(sv, b.saved.peak);
+    if (ws_bytes) *ws_bytes = std::max(w1, b.ws.peak);
+    return HS_OK;
+}
+hs_status hs_resblock_fwd(const hs_resblock_desc* d, const void* x, void* y, void* saved, int64_t saved_bytes, void* ws,
+                          int64_t ws_bytes, void* stream) {
+    HS_REQUIRE(d && x && y && saved && ws, "resblock_fwd: null argument");
+    PLAN_CHECK("resblock_fwd", d->dtype, saved_bytes, ws_bytes, resblock_fwd_run(r, *d, x, y));
+    Run r;
+    run_init(r, d->dtype, false, saved, saved_bytes, ws, ws_bytes, (hipStream_t)stream);
+    return resblock_fwd_run(r, *d, x, y);
+}
+hs_status hs_resblock_bwd(const hs_resblock_desc* d, const void* x, const void* y, const void* dy, void* dx, void* saved,
+                          int64_t saved_bytes, void* ws, int64_t ws_bytes, void* stream) {
+    HS_REQUIRE(d && x && y && dy && saved && ws, "resblock_bwd: null argument");
+    PLAN_CHECK("resblock_bwd", d->dtype, saved_bytes, ws_bytes, resblock_bwd_run(r, *d, x, y, dy, dx));
+    Run r;
+    run_init(r, d->dtype, false, saved, saved_bytes, ws, ws_bytes, (hipStream_t)stream);
+    return resblock_bwd_run(r, *d, x, y, dy, dx);
+}
+
+hs_status hs_stem_query(const hs_stem_desc* d, int64_t* saved_bytes, int64_t* ws_bytes) {
+    HS_REQUIRE(d, "stem_query: null desc");
+    Run r;
+    run_init(r, d->dtype, true, nullptr, 0, nullptr, 0, nullptr);
+    HS_PROPAGATE(stem_fwd_run(r, *d, nullptr, nullptr));
+    const long long sv = r.saved.peak, w1 = r.ws.peak;
+    Run b;
+    run_init(b, d->dtype, true, nullptr, 0, nullptr, 0, nullptr);
+    hs_stem_desc dd = *d;
+    float dummy;
+    if (!dd.cb.dw) dd.cb.dw = &dummy;   // size the workspace for the trainable case
+    HS_PROPAGATE(stem_bwd_run(b, dd, nullptr, nullptr));
+    if (saved_bytes) *saved_bytes = std::max(sv, b.saved.peak);
+    if (ws_bytes) *ws_bytes = std::max(w1, b.ws.peak);
+    return HS_OK;
+}
+hs_status hs_stem_fwd(const hs_stem_desc* d, const float* image, void* y, void* saved, int64_t saved_bytes, void* ws,
+                      int64_t ws_bytes, void* stream) {
+    HS_REQUIRE(d && image && y && saved && ws, "stem_fwd: null argument");
+    PLAN_CHECK("stem_fwd", d->dtype, saved_bytes, ws_bytes, stem_fwd_run(r, *d, image, y));
+    Run r;
+    run_init(r, d->dtype, false, saved, saved_bytes, ws, ws_bytes, (hipStream_t)stream);
+    return stem_fwd_run(r, *d, image, y);
+}
+hs_status hs_stem_bwd(const hs_stem_desc* d, const void* y, const void* dy, void* saved, int64_t saved_bytes, void* ws,
+                      int64_t ws_bytes, void* stream) {
+    HS_REQUIRE(d && dy && saved && ws, "stem_bwd: null argument");
+    PLAN_CHECK("stem_bwd", d->dtype, saved_bytes, ws_bytes, stem_bwd_run(r, *d, y, dy));
+    Run r;
+    run_init(r, d->dtype, false, saved, saved_bytes, ws, ws_bytes, (hipStream_t)stream);
+    return stem_bwd_run(r, *d, y, dy);
+}
+
+hs_status hs_bert_layer_query(const hs_bert_layer_desc* d, int64_t* saved_bytes, int64_t* ws_bytes) {
+    HS_REQUIRE(d, "bert_layer_query: null desc");
+    Run r;
+    run_init(r, d->dtype, true, nullptr, 0, nullptr, 0, nullptr);
+    HS_PROPAGATE(bert_layer_fwd_run(r, *d, nullptr, nullptr));
+    const long long sv = r.saved.peak, w1 = r.ws.peak;
+    Run b;
+    run_init(b, d->dtype, true, nullptr, 0, nullptr, 0, nullptr);
+    hs_bert_layer_desc dd = *d;
+    float dummy;
+    hs_linear* ls[6] = {&dd.q, &dd.k, &dd.v, &dd.ao, &dd.inter_l, &dd.out_l};
+    for (auto* l : ls) {   // size the workspace for the trainable case
+        if (!l->dw) l->dw = &dummy;
+        if (!l->db) l->db = &dummy;
+    }
+    int dmy;
+    HS_PROPAGATE(bert_layer_bwd_run(b, dd, nullptr, nullptr, &dmy));
+    if (saved_bytes) *saved_bytes = std::max(sv, b.saved.peak);
+    if (ws_bytes) *ws_bytes = std::max(w1, b.ws.peak);
+    return HS_OK;
+}
+hs_status hs_bert_layer_fwd(const hs_bert_layer_desc* d, const void* x, void* y, void* saved, int64_t saved_bytes,
+                            void* ws, int64_t ws_bytes, void* stream) {
+    HS_REQUIRE(d && x && y && saved && ws, "bert_layer_fwd: null argument");
+    PLAN_CHECK("bert_layer_fwd", d->dtype, saved_bytes, ws_bytes, bert_layer_fwd_run(r, *d, x, y));
+    Run r;
+    run_init(r, d->dtype, false, saved, saved_bytes, ws, ws_bytes, (hipStream_t)stream);
+    return bert_layer_fwd_run(r, *d, x, y);
+}
+hs_status hs_bert_layer_bwd(const hs_bert_layer_desc* d, const void* x, const void* dy, void* dx, void* saved,
+                            int64_t saved_bytes, void* ws, int64_t ws_bytes, void* stream) {
+    HS_REQUIRE(d && x && dy && saved && ws, "bert_layer_bwd: null argument");
+    PLAN_CHECK("bert_layer_bwd", d->dtype, saved_bytes, ws_bytes, bert_layer_bwd_run(r, *d, x, dy, dx));
+    Run r;
+    run_init(r, d->dtype, false, saved, saved_bytes, ws, ws_bytes, (hipStream_t)stream);
+    return bert_layer_bwd_run(r, *d, x, dy, dx);
+}
+
+hs_status hs_linear_fwd(int32_t dtype, const void* x, int64_t M, int32_t ldx, const hs_linear* lin, const void* w_lp,
+                        void* y, int32_t ldy, int32_t out_dtype, int32_t act, void* preact, const void* residual,
+                        int32_t ldr, float dropout_p, uint64_t seed, void* stream) {
+    HS_REQUIRE(x && lin && y && lin->w, "linear_fwd: null argument");
+    HS_REQUIRE(dtype == HS_F32 || w_lp, "linear_fwd: bf16 mode needs the bf16 weight copy");
+    Run r;
+    run_init(r, dtype, false, nullptr, 0, nullptr, 0, (hipStream_t)stream);
+    return linear_fwd_run(r, x, M, ldx, *lin, dtype == HS_F32 ? (const void*)lin->w : w_lp, y, ldy, out_dtype, act, preact,
+                          residual, ldr, dropout_p, seed);
+}
+hs_status hs_linear_bwd(int32_t dtype, const void* x, int64_t M, int32_t ldx, const hs_linear* lin, const void* w_lp,
+                        const void* dy, int32_t ldy, void* dx, int32_t lddx, int32_t dx_dtype, int32_t mul_mode,
+                        const void* mul_src, int32_t ldm, const void* dx_residual, void* ws, int64_t ws_bytes,
+                        void* stream) {
+    HS_REQUIRE(x && lin && dy && lin->w, "linear_bwd: null argument");
+    HS_REQUIRE(dtype == HS_F32 || w_lp || !dx, "linear_bwd: bf16 mode needs the bf16 weight copy");
+    PLAN_CHECK("linear_bwd", dtype, 0, ws_bytes, linear_wgrad_run(r, x, M, ldx, *lin, dy, ldy));
+    Run r;
+    run_init(r, dtype, false, nullptr, 0, ws, ws_bytes, (hipStream_t)stream);
+    HS_PROPAGATE(linear_wgrad_run(r, x, M, ldx, *lin, dy, ldy));
+    if (dx)
+        HS_PROPAGATE(linear_dgrad_run(r, *lin, dtype == HS_F32 ? (const void*)lin->w : w_lp, dy, M, ldy, dx, lddx, dx_dtype,
+                                      mul_mode, mul_src, ldm, dx_residual));
+    RUN_CHECK_ARENAS(r, "linear_bwd");
+    return HS_OK;
+}
+int64_t hs_linear_bwd_ws_bytes(int64_t M, int32_t in_f, int32_t out_f, int32_t dtype) {
+    const int split = hs_gemm_suggest_split(out_f, in_f, (int)M, dtype);
+    const long long a = split > 1 ? align_up((long long)split * out_f * in_f * 4, 256) : 256;
+    const long long b = align_up(hs_colsum_ws_bytes(M, out_f), 256);
+    return std::max(a, b) + 512;
+}
+}

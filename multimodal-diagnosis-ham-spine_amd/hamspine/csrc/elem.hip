@@ -1,0 +1,869 @@
+// HBM-bound helpers of the hot path: pooling, packing, casts, column sums, row softmax (attention),
+// BERT embeddings, softmax cross-entropy, small elementwise ops, fused AdamW.
+// 16-byte accesses wherever the layout allows, wave-shuffle reductions, no atomics except the
+// embedding scatter-add (duplicate token ids).
+#include <algorithm>
+#include "hs_common.h"
+
+namespace hs {
+
+static inline int grid_for(long long n, int cap = 4096) {
+    long long b = (n + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ============================================================================================
+// max pool (NHWC), argmax kept as a byte so the backward is a gather (deterministic, no atomics).
+// Replaces torch.nn.MaxPool2d(3, 2, 1) of the torchvision stem (reference encoder.py:63-68).
+// ============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          unsigned char* __restrict__ idx, int N, int H, int W, int C,
+                                                          int P, int Q, int ks, int st, int pad) {
+    constexpr int E = Chunk<T>::N;
+    const int cg = C / E;
+    const long long total = (long long)N * P * Q * cg;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % cg);
+        long long t = i / cg;
+        const int q = (int)(t % Q);
+        t /= Q;
+        const int p = (int)(t % P);
+        const int n = (int)(t / P);
+        float best[E];
+        unsigned char bi[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            best[e] = -INFINITY;
+            bi[e] = 0;
+        }
+        for (int r = 0; r < ks; ++r) {
+            const int h = p * st - pad + r;
+            if ((unsigned)h >= (unsigned)H) continue;
+            for (int s = 0; s < ks; ++s) {
+                const int w = q * st - pad + s;
+                if ((unsigned)w >= (unsigned)W) continue;
+                float f[E];
+                Chunk<T>::unpack(*(const u32x4*)(x + (((long long)n * H + h) * W + w) * C + c * E), f);
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (f[e] > best[e] || f[e] != f[e]) {   // first maximum wins (torch CPU scan order)
+                        best[e] = f[e];
+                        bi[e] = (unsigned char)(r * ks + s);
+                    }
+            }
+        }
+        const long long o = (((long long)n * P + p) * Q + q) * C + c * E;
+        *(u32x4*)(y + o) = Chunk<T>::pack(best);
+#pragma unroll
+        for (int e = 0; e < E; ++e) idx[o + e] = bi[e];
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                          T* __restrict__ dx, int N, int H, int W, int C, int P, int Q,
+                                                          int ks, int st, int pad) {
+    constexpr int E = Chunk<T>::N;
+    const int cg = C / E;
+    const long long total = (long long)N * H * W * cg;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % cg);
+        long long t = i / cg;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        float acc[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = 0.f;
+        const int p_lo = max(0, (h + pad - ks + st) / st), p_hi = min(P - 1, (h + pad) / st);
+        const int q_lo = max(0, (w + pad - ks + st) / st), q_hi = min(Q - 1, (w + pad) / st);
+        for (int p = p_lo; p <= p_hi; ++p)
+            for (int q = q_lo; q <= q_hi; ++q) {
+                const int r = h + pad - p * st, s = w + pad - q * st;
+                if (r < 0 || r >= ks || s < 0 || s >= ks) continue;
+                const unsigned char me = (unsigned char)(r * ks + s);
+                const long long o = (((long long)n * P + p) * Q + q) * C + c * E;
+                float g[E];
+                Chunk<T>::unpack(*(const u32x4*)(dy + o), g);
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (idx[o + e] == me) acc[e] += g[e];
+            }
+        *(u32x4*)(dx + (((long long)n * H + h) * W + w) * C + c * E) = Chunk<T>::pack(acc);
+    }
+}
+
+// ============================================================================================
+// mean over the token axis: x [B][Nt][H] -> y [B][H]   (global avg-pool / token pooling)
+// Replaces AdaptiveAvgPool2d(1) of torchvision ResNet and tokens.mean(dim=1) /
+// AdaptiveAvgPool1d(1) of the fusion modules (reference modules/fusion_blocks.py:97-98,170-178).
+// ============================================================================================
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void mean_tokens_kernel(const T* __restrict__ x, TO* __restrict__ y, int Nt, int H,
+                                                          int tpc, float scale) {
+    constexpr int E = Chunk<T>::N;
+    const int cg = H / E;
+    const int tx = threadIdx.x % tpc, ty = threadIdx.x / tpc, rp = 256 / tpc;
+    const int cc = blockIdx.x * tpc + tx;
+    const int b = blockIdx.y;
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    if (cc < cg)
+        for (int t = ty; t < Nt; t += rp) {
+            float f[E];
+            Chunk<T>::unpack(*(const u32x4*)(x + ((long long)b * Nt + t) * H + cc * E), f);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] += f[e];
+        }
+    __shared__ float sh[256 * E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) sh[threadIdx.x * E + e] = acc[e];
+    __syncthreads();
+    if (ty == 0 && cc < cg) {
+        for (int j = 1; j < rp; ++j)
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] += sh[(j * tpc + tx) * E + e];
+#pragma unroll
+        for (int e = 0; e < E; ++e) y[(long long)b * H + cc * E + e] = from_f32<TO>(acc[e] * scale);
+    }
+}
+// dx[b][t][:] = dy[b][:] * scale
+template <typename T, typename TI>
+__global__ __launch_bounds__(256) void mean_tokens_bwd_kernel(const TI* __restrict__ dy, T* __restrict__ dx, int Nt,
+                                                              int H, long long nchunks, float scale) {
+    constexpr int E = Chunk<T>::N;
+    const int cg = H / E;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % cg);
+        const long long b = i / ((long long)cg * Nt);
+        float f[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) f[e] = to_f32(dy[b * H + c * E + e]) * scale;
+        *(u32x4*)(dx + i * E) = Chunk<T>::pack(f);
+    }
+}
+
+// ============================================================================================
+// image packing for the stem: f32 NCHW [N][3][H][W] -> T [N][H+2p][Wp][4] with zero borders, so the
+// 7x7/2 conv runs as an implicit GEMM with (R=7, S=1, C=32): one filter row = 8 pixels x 4 channels.
+// ============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void pack_image_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int Cin,
+                                                         int H, int W, int Hp, int Wp, int pad) {
+    const long long total = (long long)N * Hp * Wp;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int wp = (int)(i % Wp);
+        long long t = i / Wp;
+        const int hp = (int)(t % Hp);
+        const int n = (int)(t / Hp);
+        const int h = hp - pad, w = wp - pad;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W)
+            for (int c = 0; c < Cin && c < 4; ++c) v[c] = x[(((long long)n * Cin + c) * H + h) * W + w];
+        T* o = y + i * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = from_f32<T>(v[c]);
+    }
+}
+// stem filter (K,3,7,7) stored channels_last [K][7][7][3] f32 -> T [K][7][8][4] (zero padded)
+template <typename T>
+__global__ void pack_stem_weight_kernel(const float* __restrict__ w, T* __restrict__ o, int K, int R, int S, int Cin) {
+    const int total = K * R * 8 * 4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int c = i & 3, s = (i >> 2) & 7, r = (i >> 5) % R, k = (i >> 5) / R;
+        float v = 0.f;
+        if (s < S && c < Cin) v = w[((k * R + r) * S + s) * Cin + c];
+        o[i] = from_f32<T>(v);
+    }
+}
+// f32 [K][7][8][4] gradient -> f32 [K][7][7][3]
+__global__ void unpack_stem_wgrad_kernel(const float* __restrict__ g, float* __restrict__ dw, int K, int R, int S,
+                                         int Cin) {
+    const int total = K * R * S * Cin;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int c = i % Cin, s = (i / Cin) % S, r = (i / (Cin * S)) % R, k = i / (Cin * S * R);
+        dw[i] = g[((k * R + r) * 8 + s) * 4 + c];
+    }
+}
+
+// ============================================================================================
+// multi-tensor f32 -> bf16 cast (weights, once per step in bf16 mode)
+// ============================================================================================
+struct CastTable {
+    const float* src[HS_CAST_MAX];
+    void* dst[HS_CAST_MAX];
+    long long n[HS_CAST_MAX];
+};
+__global__ __launch_bounds__(256) void cast_multi_kernel(const CastTable t) {
+    const int e = blockIdx.y;
+    const float* s = t.src[e];
+    bf16_t* d = (bf16_t*)t.dst[e];
+    const long long n = t.n[e];
+    const long long n8 = n / 8;
+    const bool al = ((((uintptr_t)s) & 15) == 0) && ((((uintptr_t)d) & 15) == 0);
+    if (al) {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+            const f32x4 a = *(const f32x4*)(s + i * 8), b = *(const f32x4*)(s + i * 8 + 4);
+            float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            *(u32x4*)(d + i * 8) = Chunk<bf16_t>::pack(f);
+        }
+        for (long long i = n8 * 8 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+            d[i] = (bf16_t)s[i];
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+            d[i] = (bf16_t)s[i];
+    }
+}
+
+// generic elementwise cast / axpby:  out = a*x + b*y  (y optional), any of f32/bf16 in and out
+template <typename TX, typename TO>
+__global__ __launch_bounds__(256) void axpby_kernel(const TX* __restrict__ x, const TX* __restrict__ y, TO* __restrict__ o,
+                                                    long long n, float a, float b) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float v = a * to_f32(x[i]);
+        if (y) v += b * to_f32(y[i]);
+        o[i] = from_f32<TO>(v);
+    }
+}
+
+// elementwise dropout (forward and backward use the same (seed, index) mask)
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ o, long long n,
+                                                      unsigned thresh, float inv_keep, unsigned long long seed) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        o[i] = from_f32<T>(to_f32(x[i]) * dropout_scale(seed, i, thresh, inv_keep));
+}
+
+// relu forward / backward (standalone; the fused forms live in the GEMM and BN epilogues)
+template <typename T>
+__global__ __launch_bounds__(256) void relu_kernel(const T* __restrict__ x, T* __restrict__ o, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        o[i] = from_f32<T>(fmaxf(to_f32(x[i]), 0.f));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                       T* __restrict__ o, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        o[i] = to_f32(y[i]) > 0.f ? dy[i] : from_f32<T>(0.f);
+}
+
+// ============================================================================================
+// column sum: X [M][N] -> out[N] (f32), used for bias gradients.  Deterministic two-stage.
+// ============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long long M, int N, int ld,
+                                                             float* __restrict__ ws) {
+    // thread per column, blockIdx.y strides rows (generic, works for any N / ld)
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float acc = 0.f;
+    for (long long r = blockIdx.y; r < M; r += gridDim.y) acc += to_f32(x[r * ld + c]);
+    ws[(long long)blockIdx.y * N + c] = acc;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ ws, int gy, int N, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float acc = 0.f;
+    for (int i = 0; i < gy; ++i) acc += ws[(long long)i * N + c];
+    out[c] = accumulate ? out[c] + acc : acc;
+}
+
+// ============================================================================================
+// attention row softmax over materialised scores (f32) with key mask and dropout.
+//   P[r][k] = softmax_k(S[r][k] + (mask[b][k] ? 0 : -big));   Pd = P * keep / (1-p)
+// Rows are (b, h, q) flattened; b = r / rows_per_batch.
+// Replaces the softmax + dropout inside torch.nn.MultiheadAttention (modules/fusion_blocks.py:48,62)
+// and transformers BertSelfAttention.
+// ============================================================================================
+constexpr int SM_MAXV = 16;   // Lk <= 1024
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, const long long* __restrict__ mask,
+                                                          T* __restrict__ P, T* __restrict__ Pd, long long rows,
+                                                          int Lk, int ldS, int ldP, int rows_per_batch,
+                                                          unsigned thresh, float inv_keep, unsigned long long seed) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const long long b = r / rows_per_batch;
+    float v[SM_MAXV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SM_MAXV; ++i) {
+        const int k = lane + 64 * i;
+        v[i] = -INFINITY;
+        if (k < Lk) {
+            float s = S[r * ldS + k];
+            if (mask && mask[b * Lk + k] == 0) s = -3.0e38f;
+            v[i] = s;
+            mx = fmaxf(mx, s);
+        }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_MAXV; ++i) {
+        const int k = lane + 64 * i;
+        if (k < Lk) {
+            v[i] = __expf(v[i] - mx);
+            sum += v[i];
+        }
+    }
+    const float inv = 1.f / wave_sum(sum);
+#pragma unroll
+    for (int i = 0; i < SM_MAXV; ++i) {
+        const int k = lane + 64 * i;
+        if (k < ldP) {
+            const float p = k < Lk ? v[i] * inv : 0.f;   // padding columns are written as zeros
+            P[r * ldP + k] = from_f32<T>(p);
+            if (Pd) {
+                const float sc = (thresh && k < Lk) ? dropout_scale(seed, (unsigned long long)r * Lk + k, thresh, inv_keep) : 1.f;
+                Pd[r * ldP + k] = from_f32<T>(p * sc);
+            }
+        }
+    }
+}
+// dS = P * (dPd - sum_k P*dPd),  dPd = dP * keep/(1-p)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dP, const T* __restrict__ P,
+                                                          T* __restrict__ dS, long long rows, int Lk, int ldG, int ldP,
+                                                          unsigned thresh, float inv_keep, unsigned long long seed) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float g[SM_MAXV], p[SM_MAXV];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_MAXV; ++i) {
+        const int k = lane + 64 * i;
+        g[i] = p[i] = 0.f;
+        if (k < Lk) {
+            float d = dP[r * ldG + k];
+            if (thresh) d *= dropout_scale(seed, (unsigned long long)r * Lk + k, thresh, inv_keep);
+            g[i] = d;
+            p[i] = to_f32(P[r * ldP + k]);
+            dot += d * p[i];
+        }
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int i = 0; i < SM_MAXV; ++i) {
+        const int k = lane + 64 * i;
+        if (k < ldP) dS[r * ldP + k] = from_f32<T>(k < Lk ? p[i] * (g[i] - dot) : 0.f);
+    }
+}
+
+// ============================================================================================
+// BERT embeddings: word[ids] + pos[l] + type[0]  (pre-LN sum saved), LayerNorm, dropout.
+// Replaces transformers BertEmbeddings.forward under reference encoder.py:131 / mibf_net/bert.py:12.
+// ============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ ids, const float* __restrict__ word,
+                                                        const float* __restrict__ pos, const float* __restrict__ type0,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        T* __restrict__ sum_out, T* __restrict__ y, float* __restrict__ mean_out,
+                                                        float* __restrict__ rstd_out, long long tokens, int L, int H, int V,
+                                                        float eps, unsigned thresh, float inv_keep, unsigned long long seed) {
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= tokens) return;
+    long long id = ids[t];
+    if (id < 0) id = 0;
+    if (id >= V) id = V - 1;
+    const int l = (int)(t % L);
+    const int nch = H / 4;
+    float v[4][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const f32x4 a = *(const f32x4*)(word + id * H + c * 4);
+            const f32x4 b = *(const f32x4*)(pos + (long long)l * H + c * 4);
+            const f32x4 d = *(const f32x4*)(type0 + c * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // the saved sum is what the backward LN sees; round it to T first so fwd == bwd inputs
+                v[i][e] = to_f32(from_f32<T>(a[e] + b[e] + d[e]));
+                s += v[i][e];
+            }
+        }
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                sq += d * d;
+            }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+    if (lane == 0) {
+        mean_out[t] = mean;
+        rstd_out[t] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int h = c * 4 + e;
+                sum_out[t * H + h] = from_f32<T>(v[i][e]);
+                float o = (v[i][e] - mean) * rstd * gamma[h] + beta[h];
+                if (thresh) o *= dropout_scale(seed, (unsigned long long)t * H + h, thresh, inv_keep);
+                y[t * H + h] = from_f32<T>(o);
+            }
+    }
+}
+// scatter-add of token gradients into the word table (atomics: duplicates of an id collide)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_word_bwd_kernel(const long long* __restrict__ ids, const T* __restrict__ dsum,
+                                                             float* __restrict__ dword, long long tokens, int H, int V) {
+    const long long total = tokens * H;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long t = i / H;
+        const int h = (int)(i % H);
+        long long id = ids[t];
+        if (id < 0) id = 0;
+        if (id >= V) id = V - 1;
+        atomicAdd(dword + id * H + h, to_f32(dsum[i]));
+    }
+}
+// dpos[l][h] = sum_b dsum[b][l][h]   (rows l >= L are zeroed by the caller)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const T* __restrict__ dsum, float* __restrict__ dpos, int B,
+                                                            int L, int H) {
+    const long long total = (long long)L * H;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc += to_f32(dsum[(long long)b * L * H + i]);
+        dpos[i] = acc;
+    }
+}
+
+// ============================================================================================
+// softmax cross-entropy with class weights and label smoothing (mean reduction), loss + dlogits.
+// Replaces nn.CrossEntropyLoss(weight, label_smoothing=0.02) (reference scripts/train.py:240,252-254)
+// and F.cross_entropy (mibf_net/model_resnet.py:88-90).  One block, rows strided over waves.
+// ============================================================================================
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                 const float* __restrict__ weight, float smoothing, int B, int C,
+                                                 float* __restrict__ loss_out, float* __restrict__ dlogits,
+                                                 float* __restrict__ row_loss) {
+    __shared__ float s_num[4], s_den[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float num = 0.f, den = 0.f;
+    for (int r = wv; r < B; r += 4) {
+        const float* z = logits + (long long)r * C;
+        float mx = -INFINITY;
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, z[c]);
+        mx = wave_max(mx);
+        float se = 0.f;
+        for (int c = lane; c < C; c += 64) se += __expf(z[c] - mx);
+        const float lse = mx + __logf(wave_sum(se));
+        const int y = (int)labels[r];
+        const float wy = weight ? weight[y] : 1.f;
+        float sm = 0.f;
+        for (int c = lane; c < C; c += 64) sm += (weight ? weight[c] : 1.f) * (lse - z[c]);
+        sm = wave_sum(sm);
+        const float l = (1.f - smoothing) * wy * (lse - z[y]) + smoothing / (float)C * sm;
+        if (lane == 0 && row_loss) row_loss[r] = l;
+        num += l;
+        den += wy;
+    }
+    if (lane == 0) {
+        s_num[wv] = num;
+        s_den[wv] = den;
+    }
+    __syncthreads();
+    const float tn = s_num[0] + s_num[1] + s_num[2] + s_num[3];
+    const float td = s_den[0] + s_den[1] + s_den[2] + s_den[3];
+    if (threadIdx.x == 0) loss_out[0] = tn / td;
+    if (!dlogits) return;
+    for (int r = wv; r < B; r += 4) {
+        const float* z = logits + (long long)r * C;
+        float mx = -INFINITY;
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, z[c]);
+        mx = wave_max(mx);
+        float se = 0.f;
+        for (int c = lane; c < C; c += 64) se += __expf(z[c] - mx);
+        const float inv = 1.f / wave_sum(se);
+        const int y = (int)labels[r];
+        const float wy = weight ? weight[y] : 1.f;
+        float wsum = 0.f;
+        for (int c = lane; c < C; c += 64) wsum += weight ? weight[c] : 1.f;
+        wsum = wave_sum(wsum);
+        for (int c = lane; c < C; c += 64) {
+            const float p = __expf(z[c] - mx) * inv;
+            const float wc = weight ? weight[c] : 1.f;
+            // d/dz_c of [(1-s) wy (lse - z_y) + s/C sum_k w_k (lse - z_k)]
+            float g = (1.f - smoothing) * wy * (p - (c == y ? 1.f : 0.f)) + smoothing / (float)C * (wsum * p - wc);
+            dlogits[(long long)r * C + c] = g / td;
+        }
+    }
+}
+
+// ============================================================================================
+// fused multi-tensor AdamW / Adam step (f32 params).  HBM-bound: 16 B read + 12 B written per param.
+// Replaces torch.optim.{Adam,AdamW}.step (reference scripts/train.py:257-261, train_resnet.py:139).
+// ============================================================================================
+struct AdamTable {
+    float* p[HS_ADAM_MAX];
+    const float* g[HS_ADAM_MAX];
+    float* m[HS_ADAM_MAX];
+    float* v[HS_ADAM_MAX];
+    long long n[HS_ADAM_MAX];
+};
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable t, float lr, float beta1, float beta2, float eps,
+                                                         float wd, float bc1, float bc2_sqrt, int decoupled,
+                                                         float grad_scale) {
+    const int e = blockIdx.y;
+    float* p = t.p[e];
+    const float* g = t.g[e];
+    float* m = t.m[e];
+    float* v = t.v[e];
+    const long long n = t.n[e];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float pi = p[i], gi = g[i] * grad_scale;
+        if (decoupled) pi *= 1.f - lr * wd;
+        else gi += wd * pi;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// host wrappers
+// --------------------------------------------------------------------------------------------
+#define DISPATCH_T(dtype, fn, ...) ((dtype) == HS_BF16 ? fn<bf16_t>(__VA_ARGS__) : fn<float>(__VA_ARGS__))
+
+template <typename T>
+static int maxpool_fwd_t(const void* x, void* y, void* idx, int N, int H, int W, int C, int P, int Q, int ks, int st,
+                         int pad, hipStream_t s) {
+    HS_REQUIRE(C % Chunk<T>::N == 0, "maxpool: C %% %d != 0", Chunk<T>::N);
+    const long long total = (long long)N * P * Q * (C / Chunk<T>::N);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, (T*)y,
+                       (unsigned char*)idx, N, H, W, C, P, Q, ks, st, pad);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+template <typename T>
+static int maxpool_bwd_t(const void* dy, const void* idx, void* dx, int N, int H, int W, int C, int P, int Q, int ks,
+                         int st, int pad, hipStream_t s) {
+    HS_REQUIRE(C % Chunk<T>::N == 0, "maxpool_bwd: C %% %d != 0", Chunk<T>::N);
+    const long long total = (long long)N * H * W * (C / Chunk<T>::N);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)dy,
+                       (const unsigned char*)idx, (T*)dx, N, H, W, C, P, Q, ks, st, pad);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+static void mean_geom(int H, int E, int& tpc, int& gx) {
+    const int cg = H / E;
+    tpc = 1;
+    while (tpc < cg && tpc < 64) tpc <<= 1;
+    gx = ceil_div(cg, tpc);
+}
+template <typename T>
+static int mean_tokens_t(const void* x, void* y, int B, int Nt, int H, int out_f32, hipStream_t s) {
+    constexpr int E = Chunk<T>::N;
+    HS_REQUIRE(H % E == 0, "mean_tokens: H %% %d != 0", E);
+    int tpc, gx;
+    mean_geom(H, E, tpc, gx);
+    if (out_f32)
+        hipLaunchKernelGGL((mean_tokens_kernel<T, float>), dim3(gx, B), dim3(256), 0, s, (const T*)x, (float*)y, Nt, H, tpc,
+                           1.f / (float)Nt);
+    else
+        hipLaunchKernelGGL((mean_tokens_kernel<T, T>), dim3(gx, B), dim3(256), 0, s, (const T*)x, (T*)y, Nt, H, tpc,
+                           1.f / (float)Nt);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+template <typename T>
+static int mean_tokens_bwd_t(const void* dy, void* dx, int B, int Nt, int H, int dy_f32, hipStream_t s) {
+    constexpr int E = Chunk<T>::N;
+    HS_REQUIRE(H % E == 0, "mean_tokens_bwd: H %% %d != 0", E);
+    const long long nch = (long long)B * Nt * H / E;
+    if (dy_f32)
+        hipLaunchKernelGGL((mean_tokens_bwd_kernel<T, float>), dim3(grid_for(nch)), dim3(256), 0, s, (const float*)dy,
+                           (T*)dx, Nt, H, nch, 1.f / (float)Nt);
+    else
+        hipLaunchKernelGGL((mean_tokens_bwd_kernel<T, T>), dim3(grid_for(nch)), dim3(256), 0, s, (const T*)dy, (T*)dx, Nt,
+                           H, nch, 1.f / (float)Nt);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+
+template <typename T>
+static int colsum_t(const void* x, long long M, int N, int ld, float* out, float* ws, long long ws_bytes, int accumulate,
+                    hipStream_t s) {
+    int gy = (int)std::min<long long>(std::max<long long>(M / 8, 1), 256);
+    HS_REQUIRE(ws && ws_bytes >= (long long)gy * N * 4, "colsum: workspace too small");
+    hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3(ceil_div(N, 256), gy), dim3(256), 0, s, (const T*)x, M, N, ld, ws);
+    HS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, ws, gy, N, out, accumulate);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+
+template <typename T>
+static int softmax_fwd_t(const float* S, const long long* mask, void* P, void* Pd, long long rows, int Lk, int ldS,
+                         int ldP, int rpb, float p, unsigned long long seed, hipStream_t s) {
+    HS_REQUIRE(Lk <= 64 * SM_MAXV && ldP <= 64 * SM_MAXV, "softmax: Lk=%d too long (max %d)", Lk, 64 * SM_MAXV);
+    const unsigned th = p > 0.f ? dropout_thresh(p) : 0u;
+    hipLaunchKernelGGL(softmax_fwd_kernel<T>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, mask, (T*)P, (T*)Pd, rows, Lk,
+                       ldS, ldP, rpb, th, p > 0.f ? 1.f / (1.f - p) : 1.f, seed);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+template <typename T>
+static int softmax_bwd_t(const float* dP, const void* P, void* dS, long long rows, int Lk, int ldG, int ldP, float p,
+                         unsigned long long seed, hipStream_t s) {
+    HS_REQUIRE(Lk <= 64 * SM_MAXV && ldP <= 64 * SM_MAXV, "softmax_bwd: Lk=%d too long", Lk);
+    const unsigned th = p > 0.f ? dropout_thresh(p) : 0u;
+    hipLaunchKernelGGL(softmax_bwd_kernel<T>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, dP, (const T*)P, (T*)dS, rows, Lk,
+                       ldG, ldP, th, p > 0.f ? 1.f / (1.f - p) : 1.f, seed);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+
+}  // namespace hs
+
+using namespace hs;
+
+extern "C" {
+
+hs_status hs_maxpool_fwd(int32_t dtype, const void* x, void* y, void* idx, int32_t N, int32_t H, int32_t W, int32_t C,
+                         int32_t ksize, int32_t stride, int32_t pad, void* stream) {
+    HS_REQUIRE(x && y && idx, "maxpool: null argument");
+    HS_REQUIRE(ksize * ksize <= 255, "maxpool: window too large");
+    const int P = (H + 2 * pad - ksize) / stride + 1, Q = (W + 2 * pad - ksize) / stride + 1;
+    return DISPATCH_T(dtype, maxpool_fwd_t, x, y, idx, N, H, W, C, P, Q, ksize, stride, pad, (hipStream_t)stream);
+}
+hs_status hs_maxpool_bwd(int32_t dtype, const void* dy, const void* idx, void* dx, int32_t N, int32_t H, int32_t W,
+                         int32_t C, int32_t ksize, int32_t stride, int32_t pad, void* stream) {
+    HS_REQUIRE(dy && dx && idx, "maxpool_bwd: null argument");
+    const int P = (H + 2 * pad - ksize) / stride + 1, Q = (W + 2 * pad - ksize) / stride + 1;
+    return DISPATCH_T(dtype, maxpool_bwd_t, dy, idx, dx, N, H, W, C, P, Q, ksize, stride, pad, (hipStream_t)stream);
+}
+hs_status hs_mean_tokens_fwd(int32_t dtype, const void* x, void* y, int32_t B, int32_t Nt, int32_t H, int32_t out_f32,
+                             void* stream) {
+    HS_REQUIRE(x && y && B > 0 && Nt > 0, "mean_tokens: bad argument");
+    return DISPATCH_T(dtype, mean_tokens_t, x, y, B, Nt, H, out_f32, (hipStream_t)stream);
+}
+hs_status hs_mean_tokens_bwd(int32_t dtype, const void* dy, void* dx, int32_t B, int32_t Nt, int32_t H, int32_t dy_f32,
+                             void* stream) {
+    HS_REQUIRE(dy && dx && B > 0 && Nt > 0, "mean_tokens_bwd: bad argument");
+    return DISPATCH_T(dtype, mean_tokens_bwd_t, dy, dx, B, Nt, H, dy_f32, (hipStream_t)stream);
+}
+hs_status hs_pack_image(int32_t dtype, const float* x, void* y, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Hp,
+                        int32_t Wp, int32_t pad, void* stream) {
+    HS_REQUIRE(x && y && Cin <= 4, "pack_image: bad argument");
+    const long long total = (long long)N * Hp * Wp;
+    if (dtype == HS_BF16)
+        hipLaunchKernelGGL(pack_image_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x,
+                           (bf16_t*)y, N, Cin, H, W, Hp, Wp, pad);
+    else
+        hipLaunchKernelGGL(pack_image_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (float*)y,
+                           N, Cin, H, W, Hp, Wp, pad);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_pack_stem_weight(int32_t dtype, const float* w, void* out, int32_t K, int32_t R, int32_t S, int32_t Cin,
+                              void* stream) {
+    HS_REQUIRE(w && out && S <= 8 && Cin <= 4, "pack_stem_weight: bad argument");
+    const int total = K * R * 32;
+    if (dtype == HS_BF16)
+        hipLaunchKernelGGL(pack_stem_weight_kernel<bf16_t>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                           (bf16_t*)out, K, R, S, Cin);
+    else
+        hipLaunchKernelGGL(pack_stem_weight_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                           (float*)out, K, R, S, Cin);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_unpack_stem_wgrad(const float* g, float* dw, int32_t K, int32_t R, int32_t S, int32_t Cin, void* stream) {
+    HS_REQUIRE(g && dw, "unpack_stem_wgrad: null argument");
+    hipLaunchKernelGGL(unpack_stem_wgrad_kernel, dim3(ceil_div(K * R * S * Cin, 256)), dim3(256), 0, (hipStream_t)stream, g,
+                       dw, K, R, S, Cin);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_cast_f32_to_bf16_multi(int32_t count, const float* const* src, void* const* dst, const int64_t* n,
+                                    void* stream) {
+    HS_REQUIRE(count >= 0 && (count == 0 || (src && dst && n)), "cast_multi: bad argument");
+    for (int base = 0; base < count; base += HS_CAST_MAX) {
+        CastTable t;
+        memset(&t, 0, sizeof(t));
+        const int cnt = std::min(HS_CAST_MAX, count - base);
+        long long mx = 0;
+        for (int i = 0; i < cnt; ++i) {
+            t.src[i] = src[base + i];
+            t.dst[i] = dst[base + i];
+            t.n[i] = n[base + i];
+            mx = std::max<long long>(mx, t.n[i]);
+        }
+        const int gx = (int)std::min<long long>(std::max<long long>((mx / 8 + 255) / 256, 1), 256);
+        hipLaunchKernelGGL(cast_multi_kernel, dim3(gx, cnt), dim3(256), 0, (hipStream_t)stream, t);
+        HS_LAUNCH_CHECK();
+    }
+    return HS_OK;
+}
+hs_status hs_axpby(int32_t in_dtype, int32_t out_dtype, const void* x, const void* y, void* out, int64_t n, float a,
+                   float b, void* stream) {
+    HS_REQUIRE(x && out && n >= 0, "axpby: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(grid_for(n)), bl(256);
+    if (in_dtype == HS_BF16 && out_dtype == HS_BF16)
+        hipLaunchKernelGGL((axpby_kernel<bf16_t, bf16_t>), g, bl, 0, s, (const bf16_t*)x, (const bf16_t*)y, (bf16_t*)out, n, a, b);
+    else if (in_dtype == HS_BF16)
+        hipLaunchKernelGGL((axpby_kernel<bf16_t, float>), g, bl, 0, s, (const bf16_t*)x, (const bf16_t*)y, (float*)out, n, a, b);
+    else if (out_dtype == HS_BF16)
+        hipLaunchKernelGGL((axpby_kernel<float, bf16_t>), g, bl, 0, s, (const float*)x, (const float*)y, (bf16_t*)out, n, a, b);
+    else
+        hipLaunchKernelGGL((axpby_kernel<float, float>), g, bl, 0, s, (const float*)x, (const float*)y, (float*)out, n, a, b);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_dropout(int32_t dtype, const void* x, void* out, int64_t n, float p, uint64_t seed, void* stream) {
+    HS_REQUIRE(x && out && p >= 0.f && p < 1.f, "dropout: bad argument");
+    const unsigned th = dropout_thresh(p);
+    const float ik = 1.f / (1.f - p);
+    if (dtype == HS_BF16)
+        hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           (bf16_t*)out, n, th, ik, seed);
+    else
+        hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                           (float*)out, n, th, ik, seed);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_relu_fwd(int32_t dtype, const void* x, void* out, int64_t n, void* stream) {
+    HS_REQUIRE(x && out, "relu: null argument");
+    if (dtype == HS_BF16)
+        hipLaunchKernelGGL(relu_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, n);
+    else
+        hipLaunchKernelGGL(relu_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, n);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_relu_bwd(int32_t dtype, const void* dy, const void* y, void* dx, int64_t n, void* stream) {
+    HS_REQUIRE(dy && y && dx, "relu_bwd: null argument");
+    if (dtype == HS_BF16)
+        hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                           (const bf16_t*)y, (bf16_t*)dx, n);
+    else
+        hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
+                           (const float*)y, (float*)dx, n);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_colsum(int32_t dtype, const void* x, int64_t M, int32_t N, int32_t ld, float* out, void* ws,
+                    int64_t ws_bytes, int32_t accumulate, void* stream) {
+    HS_REQUIRE(x && out && M > 0 && N > 0, "colsum: bad argument");
+    return DISPATCH_T(dtype, colsum_t, x, M, N, ld, out, (float*)ws, ws_bytes, accumulate, (hipStream_t)stream);
+}
+int64_t hs_colsum_ws_bytes(int64_t M, int32_t N) {
+    return std::min<long long>(std::max<long long>(M / 8, 1), 256) * N * 4;
+}
+hs_status hs_softmax_fwd(int32_t dtype, const float* S, const int64_t* mask, void* P, void* P_drop, int64_t rows,
+                         int32_t Lk, int32_t ldS, int32_t ldP, int32_t rows_per_batch, float dropout_p, uint64_t seed,
+                         void* stream) {
+    HS_REQUIRE(S && P && rows > 0 && Lk > 0 && rows_per_batch > 0, "softmax: bad argument");
+    return DISPATCH_T(dtype, softmax_fwd_t, S, (const long long*)mask, P, P_drop, rows, Lk, ldS, ldP, rows_per_batch,
+                      dropout_p, seed, (hipStream_t)stream);
+}
+hs_status hs_softmax_bwd(int32_t dtype, const float* dP, const void* P, void* dS, int64_t rows, int32_t Lk, int32_t ldG,
+                         int32_t ldP, float dropout_p, uint64_t seed, void* stream) {
+    HS_REQUIRE(dP && P && dS && rows > 0 && Lk > 0, "softmax_bwd: bad argument");
+    return DISPATCH_T(dtype, softmax_bwd_t, dP, P, dS, rows, Lk, ldG, ldP, dropout_p, seed, (hipStream_t)stream);
+}
+hs_status hs_bert_embed_fwd(int32_t dtype, const int64_t* ids, const float* word, const float* pos, const float* type0,
+                            const float* gamma, const float* beta, void* sum_out, void* y, float* mean, float* rstd,
+                            int64_t tokens, int32_t L, int32_t H, int32_t V, float eps, float dropout_p, uint64_t seed,
+                            void* stream) {
+    HS_REQUIRE(ids && word && pos && type0 && gamma && beta && sum_out && y && mean && rstd, "bert_embed: null argument");
+    HS_REQUIRE(H % 4 == 0 && H <= 1024, "bert_embed: H=%d unsupported", H);
+    const unsigned th = dropout_p > 0.f ? dropout_thresh(dropout_p) : 0u;
+    const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    const dim3 g(ceil_div(tokens, 4)), b(256);
+    if (dtype == HS_BF16)
+        hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, (const long long*)ids, word, pos, type0,
+                           gamma, beta, (bf16_t*)sum_out, (bf16_t*)y, mean, rstd, tokens, L, H, V, eps, th, ik, seed);
+    else
+        hipLaunchKernelGGL(embed_fwd_kernel<float>, g, b, 0, (hipStream_t)stream, (const long long*)ids, word, pos, type0,
+                           gamma, beta, (float*)sum_out, (float*)y, mean, rstd, tokens, L, H, V, eps, th, ik, seed);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_bert_embed_bwd(int32_t dtype, const int64_t* ids, const void* dsum, float* dword, float* dpos, int32_t B,
+                            int32_t L, int32_t H, int32_t V, void* stream) {
+    HS_REQUIRE(ids && dsum, "bert_embed_bwd: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const long long tokens = (long long)B * L;
+    if (dword) {   // caller zero-fills dword first
+        if (dtype == HS_BF16)
+            hipLaunchKernelGGL(embed_word_bwd_kernel<bf16_t>, dim3(grid_for(tokens * H)), dim3(256), 0, s,
+                               (const long long*)ids, (const bf16_t*)dsum, dword, tokens, H, V);
+        else
+            hipLaunchKernelGGL(embed_word_bwd_kernel<float>, dim3(grid_for(tokens * H)), dim3(256), 0, s,
+                               (const long long*)ids, (const float*)dsum, dword, tokens, H, V);
+        HS_LAUNCH_CHECK();
+    }
+    if (dpos) {
+        if (dtype == HS_BF16)
+            hipLaunchKernelGGL(embed_pos_bwd_kernel<bf16_t>, dim3(grid_for((long long)L * H)), dim3(256), 0, s,
+                               (const bf16_t*)dsum, dpos, B, L, H);
+        else
+            hipLaunchKernelGGL(embed_pos_bwd_kernel<float>, dim3(grid_for((long long)L * H)), dim3(256), 0, s,
+                               (const float*)dsum, dpos, B, L, H);
+        HS_LAUNCH_CHECK();
+    }
+    return HS_OK;
+}
+hs_status hs_cross_entropy(const float* logits, const int64_t* labels, const float* weight, float label_smoothing,
+                           int32_t B, int32_t C, float* loss, float* dlogits, float* row_loss, void* stream) {
+    HS_REQUIRE(logits && labels && loss && B > 0 && C > 0, "cross_entropy: bad argument");
+    hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, (const long long*)labels, weight,
+                       label_smoothing, B, C, loss, dlogits, row_loss);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_adam_step_multi(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                             float* const* exp_avg_sq, const int64_t* n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int32_t step, int32_t decoupled, float grad_scale, void* stream) {
+    HS_REQUIRE(count >= 0 && step >= 1, "adam: bad argument");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    for (int base = 0; base < count; base += HS_ADAM_MAX) {
+        AdamTable t;
+        memset(&t, 0, sizeof(t));
+        const int cnt = std::min(HS_ADAM_MAX, count - base);
+        long long mx = 0;
+        for (int i = 0; i < cnt; ++i) {
+            t.p[i] = params[base + i];
+            t.g[i] = grads[base + i];
+            t.m[i] = exp_avg[base + i];
+            t.v[i] = exp_avg_sq[base + i];
+            t.n[i] = n[base + i];
+            mx = std::max<long long>(mx, t.n[i]);
+        }
+        const int gx = (int)std::min<long long>(std::max<long long>((mx + 1023) / 1024, 1), 512);
+        hipLaunchKernelGGL(adam_multi_kernel, dim3(gx, cnt), dim3(256), 0, (hipStream_t)stream, t, lr, beta1, beta2, eps,
+                           weight_decay, bc1, bc2s, decoupled, grad_scale);
+        HS_LAUNCH_CHECK();
+    }
+    return HS_OK;
+}
+}

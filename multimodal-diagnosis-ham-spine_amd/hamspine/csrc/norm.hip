@@ -1,0 +1,553 @@
+// BatchNorm (train/eval, NHWC) and LayerNorm forward/backward -- HBM-bound kernels.
+// All 16-byte vector accesses, f32 statistics, deterministic two-stage column reductions.
+//
+// Replaces torch.nn.BatchNorm2d inside torchvision's ResNet blocks (reference encoder.py:35-42,
+// mibf_net/model_resnet.py:15) and torch.nn.LayerNorm (modules/fusion_blocks.py:17-34, heads.py:36,
+// transformers BertEmbeddings / BertSelfOutput / BertOutput LayerNorm, eps 1e-12).
+#include <algorithm>
+#include "hs_common.h"
+
+namespace hs {
+
+// --------------------------------------------------------------------------------------------
+// generic column-reduction geometry over a row-major [M][C] matrix (C % chunk == 0)
+// --------------------------------------------------------------------------------------------
+struct ColGeom {
+    int cg;        // chunk columns = C / EPC
+    int tpc;       // threads across columns (<=256, power of two divides 256)
+    int rows_par;  // 256 / tpc
+    int gx, gy;    // grid
+};
+static ColGeom col_geom(long long M, int C, int epc) {
+    ColGeom g;
+    g.cg = C / epc;
+    int tpc = 1;
+    while (tpc < g.cg && tpc < 256) tpc <<= 1;
+    g.tpc = tpc;
+    g.rows_par = 256 / tpc;
+    g.gx = ceil_div(g.cg, tpc);
+    long long want = 2048 / g.gx;
+    if (want < 1) want = 1;
+    long long maxy = ceil_div(M, (long long)g.rows_par * 4);   // >= 4 rows per thread
+    if (maxy < 1) maxy = 1;
+    g.gy = (int)(want < maxy ? want : maxy);
+    return g;
+}
+
+// ============================================================================================
+// BatchNorm
+// ============================================================================================
+// stage 1: per (row block, channel) Welford partials (count, mean, M2)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const T* __restrict__ x, long long M, int C, int tpc,
+                                                               float* __restrict__ ws) {
+    constexpr int E = Chunk<T>::N;
+    const int cg = C / E;
+    const int tx = threadIdx.x % tpc, ty = threadIdx.x / tpc, rows_par = 256 / tpc;
+    const int cc = blockIdx.x * tpc + tx;
+    float mean[E], m2[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) mean[e] = m2[e] = 0.f;
+    float cnt = 0.f;
+    if (cc < cg) {
+        for (long long r = (long long)blockIdx.y * rows_par + ty; r < M; r += (long long)gridDim.y * rows_par) {
+            const u32x4 c = *(const u32x4*)(x + r * C + (long long)cc * E);
+            float f[E];
+            Chunk<T>::unpack(c, f);
+            cnt += 1.f;
+            const float inv = 1.f / cnt;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float d = f[e] - mean[e];
+                mean[e] += d * inv;
+                m2[e] += d * (f[e] - mean[e]);
+            }
+        }
+    }
+    // merge across ty through LDS (fixed order -> deterministic)
+    __shared__ float s_cnt[256];
+    __shared__ float s_mean[256 * E];
+    __shared__ float s_m2[256 * E];
+    s_cnt[threadIdx.x] = cnt;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        s_mean[threadIdx.x * E + e] = mean[e];
+        s_m2[threadIdx.x * E + e] = m2[e];
+    }
+    __syncthreads();
+    if (ty == 0 && cc < cg) {
+        for (int j = 1; j < rows_par; ++j) {
+            const int o = j * tpc + tx;
+            const float nb = s_cnt[o];
+            if (nb > 0.f) {
+                const float n = cnt + nb;
+                const float w = nb / n;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const float d = s_mean[o * E + e] - mean[e];
+                    mean[e] += d * w;
+                    m2[e] += s_m2[o * E + e] + d * d * cnt * w;
+                }
+                cnt = n;
+            }
+        }
+        float* o = ws + ((long long)blockIdx.y * C + (long long)cc * E) * 3;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            o[e * 3 + 0] = cnt;
+            o[e * 3 + 1] = mean[e];
+            o[e * 3 + 2] = m2[e];
+        }
+    }
+}
+
+// stage 2: merge row blocks; produce mean / invstd / (scale, shift); update running statistics
+__global__ void bn_stats_final_kernel(const float* __restrict__ ws, int gy, int C, long long M, float eps,
+                                      float momentum, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, float* __restrict__ running_mean,
+                                      float* __restrict__ running_var, float* __restrict__ mean_out,
+                                      float* __restrict__ invstd_out, float* __restrict__ scale_out,
+                                      float* __restrict__ shift_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+    for (int b = 0; b < gy; ++b) {
+        const float* p = ws + ((long long)b * C + c) * 3;
+        const float nb = p[0];
+        if (nb > 0.f) {
+            const float n = cnt + nb;
+            const float d = p[1] - mean;
+            const float w = nb / n;
+            mean += d * w;
+            m2 += p[2] + d * d * cnt * w;
+            cnt = n;
+        }
+    }
+    const float var = m2 / (float)M;                   // biased, used for normalisation
+    const float invstd = rsqrtf(var + eps);
+    mean_out[c] = mean;
+    invstd_out[c] = invstd;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale_out[c] = g * invstd;
+    shift_out[c] = b - mean * g * invstd;
+    if (running_mean) {
+        const float unbiased = M > 1 ? m2 / (float)(M - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+// eval mode: scale/shift from running statistics
+__global__ void bn_eval_scale_kernel(int C, float eps, const float* gamma, const float* beta,
+                                     const float* running_mean, const float* running_var, float* mean_out,
+                                     float* invstd_out, float* scale_out, float* shift_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = rsqrtf(running_var[c] + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    mean_out[c] = running_mean[c];
+    invstd_out[c] = invstd;
+    scale_out[c] = g * invstd;
+    shift_out[c] = b - running_mean[c] * g * invstd;
+}
+
+// y = x*scale + shift (+ residual) (relu)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const T* __restrict__ res,
+                                                       T* __restrict__ y, long long nchunks, int cg, int relu) {
+    constexpr int E = Chunk<T>::N;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long long)gridDim.x * 256) {
+        const int c0 = (int)(i % cg) * E;
+        float f[E], r[E];
+        Chunk<T>::unpack(*(const u32x4*)(x + i * E), f);
+        if (res) Chunk<T>::unpack(*(const u32x4*)(res + i * E), r);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            float v = f[e] * scale[c0 + e] + shift[c0 + e];
+            if (res) v += r[e];
+            if (relu) v = fmaxf(v, 0.f);
+            f[e] = v;
+        }
+        *(u32x4*)(y + i * E) = Chunk<T>::pack(f);
+    }
+}
+
+// backward stage 1: per (row block, channel) sums of dz and dz*xhat, dz = dy * (y > 0 if relu)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                             const T* __restrict__ x, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, long long M, int C,
+                                                             int tpc, int relu, float* __restrict__ ws) {
+    constexpr int E = Chunk<T>::N;
+    const int cg = C / E;
+    const int tx = threadIdx.x % tpc, ty = threadIdx.x / tpc, rows_par = 256 / tpc;
+    const int cc = blockIdx.x * tpc + tx;
+    float s1[E], s2[E], mu[E], is[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) s1[e] = s2[e] = mu[e] = is[e] = 0.f;
+    if (cc < cg) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            mu[e] = mean[cc * E + e];
+            is[e] = invstd[cc * E + e];
+        }
+        for (long long r = (long long)blockIdx.y * rows_par + ty; r < M; r += (long long)gridDim.y * rows_par) {
+            const long long o = r * C + (long long)cc * E;
+            float g[E], xv[E], yv[E];
+            Chunk<T>::unpack(*(const u32x4*)(dy + o), g);
+            Chunk<T>::unpack(*(const u32x4*)(x + o), xv);
+            if (relu) Chunk<T>::unpack(*(const u32x4*)(y + o), yv);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float dz = (relu && !(yv[e] > 0.f)) ? 0.f : g[e];
+                s1[e] += dz;
+                s2[e] += dz * (xv[e] - mu[e]) * is[e];
+            }
+        }
+    }
+    __shared__ float sh1[256 * E];
+    __shared__ float sh2[256 * E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        sh1[threadIdx.x * E + e] = s1[e];
+        sh2[threadIdx.x * E + e] = s2[e];
+    }
+    __syncthreads();
+    if (ty == 0 && cc < cg) {
+        for (int j = 1; j < rows_par; ++j) {
+            const int o = j * tpc + tx;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                s1[e] += sh1[o * E + e];
+                s2[e] += sh2[o * E + e];
+            }
+        }
+        float* o = ws + ((long long)blockIdx.y * C + (long long)cc * E) * 2;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            o[e * 2 + 0] = s1[e];
+            o[e * 2 + 1] = s2[e];
+        }
+    }
+}
+__global__ void bn_bwd_final_kernel(const float* __restrict__ ws, int gy, int C, float* __restrict__ dbeta,
+                                    float* __restrict__ dgamma) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < gy; ++i) {
+        a += ws[((long long)i * C + c) * 2 + 0];
+        b += ws[((long long)i * C + c) * 2 + 1];
+    }
+    dbeta[c] = a;
+    dgamma[c] = b;
+}
+// backward stage 2: dx = gamma*invstd*(dz - dbeta/M - xhat*dgamma/M)  [train]   |  gamma*invstd*dz  [eval]
+// optional dres = dz (gradient of the residual branch)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                           const T* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ dbeta,
+                                                           const float* __restrict__ dgamma, T* __restrict__ dx,
+                                                           T* __restrict__ dres, long long nchunks, int cg, float invM,
+                                                           int relu, int train) {
+    constexpr int E = Chunk<T>::N;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long long)gridDim.x * 256) {
+        const int c0 = (int)(i % cg) * E;
+        float g[E], xv[E], yv[E], o[E];
+        Chunk<T>::unpack(*(const u32x4*)(dy + i * E), g);
+        if (train) Chunk<T>::unpack(*(const u32x4*)(x + i * E), xv);
+        if (relu) Chunk<T>::unpack(*(const u32x4*)(y + i * E), yv);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int c = c0 + e;
+            const float dz = (relu && !(yv[e] > 0.f)) ? 0.f : g[e];
+            g[e] = dz;
+            const float sc = (gamma ? gamma[c] : 1.f) * invstd[c];
+            if (train) {
+                const float xh = (xv[e] - mean[c]) * invstd[c];
+                o[e] = sc * (dz - dbeta[c] * invM - xh * dgamma[c] * invM);
+            } else {
+                o[e] = sc * dz;
+            }
+        }
+        *(u32x4*)(dx + i * E) = Chunk<T>::pack(o);
+        if (dres) *(u32x4*)(dres + i * E) = Chunk<T>::pack(g);
+    }
+}
+
+template <typename T>
+static int bn_fwd_t(const hs_bn_params* p, hipStream_t s) {
+    constexpr int E = Chunk<T>::N;
+    HS_REQUIRE(p->C % E == 0, "bn: C %% %d != 0", E);
+    const long long M = p->M;
+    const int C = p->C;
+    if (p->training) {
+        ColGeom g = col_geom(M, C, E);
+        HS_REQUIRE(p->ws && p->ws_bytes >= (long long)g.gy * C * 3 * 4, "bn: workspace too small");
+        hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(g.gx, g.gy), dim3(256), 0, s, (const T*)p->x, M, C, g.tpc,
+                           (float*)p->ws);
+        HS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, (const float*)p->ws, g.gy, C, M,
+                           p->eps, p->momentum, p->gamma, p->beta, p->running_mean, p->running_var, p->save_mean,
+                           p->save_invstd, p->scale, p->shift);
+        HS_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(bn_eval_scale_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, C, p->eps, p->gamma, p->beta,
+                           p->running_mean, p->running_var, p->save_mean, p->save_invstd, p->scale, p->shift);
+        HS_LAUNCH_CHECK();
+    }
+    if (p->y) {
+        const long long nch = M * C / E;
+        const int blocks = (int)std::min<long long>((nch + 255) / 256, 4096);
+        hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(blocks), dim3(256), 0, s, (const T*)p->x, p->scale, p->shift,
+                           (const T*)p->residual, (T*)p->y, nch, C / E, p->relu);
+        HS_LAUNCH_CHECK();
+    }
+    return HS_OK;
+}
+
+template <typename T>
+static int bn_bwd_t(const hs_bn_bwd_params* p, hipStream_t s) {
+    constexpr int E = Chunk<T>::N;
+    HS_REQUIRE(p->C % E == 0, "bn_bwd: C %% %d != 0", E);
+    const long long M = p->M;
+    const int C = p->C;
+    ColGeom g = col_geom(M, C, E);
+    HS_REQUIRE(p->ws && p->ws_bytes >= (long long)g.gy * C * 2 * 4, "bn_bwd: workspace too small");
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(g.gx, g.gy), dim3(256), 0, s, (const T*)p->dy, (const T*)p->y,
+                       (const T*)p->x, p->save_mean, p->save_invstd, M, C, g.tpc, p->relu, (float*)p->ws);
+    HS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, (const float*)p->ws, g.gy, C,
+                       p->dbeta, p->dgamma);
+    HS_LAUNCH_CHECK();
+    if (p->dx) {
+        const long long nch = M * C / E;
+        const int blocks = (int)std::min<long long>((nch + 255) / 256, 4096);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(blocks), dim3(256), 0, s, (const T*)p->dy, (const T*)p->y,
+                           (const T*)p->x, p->save_mean, p->save_invstd, p->gamma, p->dbeta, p->dgamma, (T*)p->dx,
+                           (T*)p->dres, nch, C / E, 1.f / (float)M, p->relu, p->training);
+        HS_LAUNCH_CHECK();
+    }
+    return HS_OK;
+}
+
+int bn_fwd(const hs_bn_params* p, hipStream_t s) {
+    HS_REQUIRE(p && p->x && p->scale && p->shift && p->save_mean && p->save_invstd, "bn: null argument");
+    return p->dtype == HS_BF16 ? bn_fwd_t<bf16_t>(p, s) : bn_fwd_t<float>(p, s);
+}
+int bn_bwd(const hs_bn_bwd_params* p, hipStream_t s) {
+    HS_REQUIRE(p && p->dy && p->x && p->dbeta && p->dgamma, "bn_bwd: null argument");
+    return p->dtype == HS_BF16 ? bn_bwd_t<bf16_t>(p, s) : bn_bwd_t<float>(p, s);
+}
+long long bn_ws_bytes(long long M, int C, int dtype) {
+    ColGeom g = col_geom(M, C, dtype == HS_BF16 ? 8 : 4);
+    return (long long)g.gy * C * 3 * 4;
+}
+
+// ============================================================================================
+// LayerNorm: one wave per row, row cached in registers (H <= 64 * E * LN_MAXV)
+// ============================================================================================
+constexpr int LN_MAXV = 4;   // chunks per lane: H <= 64*8*4 = 2048 (bf16) / 1024 (f32)
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     long long M, int H, float eps) {
+    constexpr int E = Chunk<T>::N;
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nch = H / E;
+    float v[LN_MAXV][E];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            Chunk<T>::unpack(*(const u32x4*)(x + row * H + (long long)c * E), v[i]);
+#pragma unroll
+            for (int e = 0; e < E; ++e) sum += v[i][e];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float d = v[i][e] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            float o[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) o[e] = (v[i][e] - mean) * rstd * gamma[c * E + e] + beta[c * E + e];
+            *(u32x4*)(y + row * H + (long long)c * E) = Chunk<T>::pack(o);
+        }
+    }
+}
+
+// backward: each wave walks rows (stride = total waves), writes dx and keeps per-lane dgamma/dbeta
+// partials which are written to ws[wave][2][H]; a second kernel reduces over waves.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, T* __restrict__ dx,
+                                                     float* __restrict__ ws, long long M, int H) {
+    constexpr int E = Chunk<T>::N;
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const int nch = H / E;
+    float dg[LN_MAXV][E], db[LN_MAXV][E], gm[LN_MAXV][E];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            dg[i][e] = db[i][e] = 0.f;
+            const int c = lane + 64 * i;
+            gm[i][e] = c < nch ? gamma[c * E + e] : 0.f;
+        }
+    for (long long row = wid; row < M; row += nw) {
+        const float mu = mean[row], rs = rstd[row];
+        float g[LN_MAXV][E], xh[LN_MAXV][E];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                float xv[E];
+                Chunk<T>::unpack(*(const u32x4*)(dy + row * H + (long long)c * E), g[i]);
+                Chunk<T>::unpack(*(const u32x4*)(x + row * H + (long long)c * E), xv);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    xh[i][e] = (xv[e] - mu) * rs;
+                    dg[i][e] += g[i][e] * xh[i][e];
+                    db[i][e] += g[i][e];
+                    const float gg = g[i][e] * gm[i][e];
+                    s1 += gg;
+                    s2 += gg * xh[i][e];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)H;
+        s2 = wave_sum(s2) / (float)H;
+        if (dx) {
+#pragma unroll
+            for (int i = 0; i < LN_MAXV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nch) {
+                    float o[E];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) o[e] = rs * (g[i][e] * gm[i][e] - s1 - xh[i][e] * s2);
+                    *(u32x4*)(dx + row * H + (long long)c * E) = Chunk<T>::pack(o);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                ws[((long long)wid * 2 + 0) * H + c * E + e] = dg[i][e];
+                ws[((long long)wid * 2 + 1) * H + c * E + e] = db[i][e];
+            }
+        }
+    }
+}
+__global__ void ln_bwd_final_kernel(const float* __restrict__ ws, int nw, int H, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= H) return;
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < nw; ++w) {
+        a += ws[((long long)w * 2 + 0) * H + c];
+        b += ws[((long long)w * 2 + 1) * H + c];
+    }
+    dgamma[c] = a;
+    dbeta[c] = b;
+}
+
+static int ln_bwd_blocks(long long M) {
+    long long b = (M + 15) / 16;   // >= 4 rows per wave
+    if (b > 256) b = 256;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+template <typename T>
+static int ln_fwd_t(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                    long long M, int H, float eps, hipStream_t s) {
+    constexpr int E = Chunk<T>::N;
+    HS_REQUIRE(H % E == 0 && H <= 64 * E * LN_MAXV, "layernorm: H=%d unsupported for this dtype", H);
+    hipLaunchKernelGGL(ln_fwd_kernel<T>, dim3(ceil_div(M, 4)), dim3(256), 0, s, (const T*)x, gamma, beta, (T*)y, mean,
+                       rstd, M, H, eps);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+template <typename T>
+static int ln_bwd_t(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                    void* dx, float* dgamma, float* dbeta, float* ws, long long ws_bytes, long long M, int H,
+                    hipStream_t s) {
+    constexpr int E = Chunk<T>::N;
+    HS_REQUIRE(H % E == 0 && H <= 64 * E * LN_MAXV, "layernorm_bwd: H=%d unsupported for this dtype", H);
+    const int blocks = ln_bwd_blocks(M);
+    HS_REQUIRE(ws && ws_bytes >= (long long)blocks * 4 * 2 * H * 4, "layernorm_bwd: workspace too small");
+    hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3(blocks), dim3(256), 0, s, (const T*)dy, (const T*)x, gamma, mean, rstd,
+                       (T*)dx, ws, M, H);
+    HS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3(ceil_div(H, 256)), dim3(256), 0, s, ws, blocks * 4, H, dgamma, dbeta);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+
+int ln_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+           long long M, int H, float eps, hipStream_t s) {
+    HS_REQUIRE(x && gamma && beta && y, "layernorm: null argument");
+    return dtype == HS_BF16 ? ln_fwd_t<bf16_t>(x, gamma, beta, y, mean, rstd, M, H, eps, s)
+                            : ln_fwd_t<float>(x, gamma, beta, y, mean, rstd, M, H, eps, s);
+}
+int ln_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+           void* dx, float* dgamma, float* dbeta, float* ws, long long ws_bytes, long long M, int H, hipStream_t s) {
+    HS_REQUIRE(dy && x && gamma && mean && rstd && dgamma && dbeta, "layernorm_bwd: null argument");
+    return dtype == HS_BF16 ? ln_bwd_t<bf16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, ws_bytes, M, H, s)
+                            : ln_bwd_t<float>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, ws_bytes, M, H, s);
+}
+long long ln_bwd_ws_bytes(long long M, int H) { return (long long)ln_bwd_blocks(M) * 4 * 2 * H * 4; }
+
+}  // namespace hs
+
+extern "C" {
+hs_status hs_batchnorm_fwd(const hs_bn_params* p, void* stream) { return hs::bn_fwd(p, (hipStream_t)stream); }
+hs_status hs_batchnorm_bwd(const hs_bn_bwd_params* p, void* stream) { return hs::bn_bwd(p, (hipStream_t)stream); }
+int64_t hs_batchnorm_ws_bytes(int64_t M, int32_t C, int32_t dtype) { return hs::bn_ws_bytes(M, C, dtype); }
+hs_status hs_layernorm_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                           float* rstd, int64_t M, int32_t H, float eps, void* stream) {
+    return hs::ln_fwd(dtype, x, gamma, beta, y, mean, rstd, M, H, eps, (hipStream_t)stream);
+}
+hs_status hs_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                           const float* rstd, void* dx, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes,
+                           int64_t M, int32_t H, void* stream) {
+    return hs::ln_bwd(dtype, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, (float*)ws, ws_bytes, M, H,
+                      (hipStream_t)stream);
+}
+int64_t hs_layernorm_bwd_ws_bytes(int64_t M, int32_t H) { return hs::ln_bwd_ws_bytes(M, H); }
+}
