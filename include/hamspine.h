@@ -206,6 +206,10 @@ hs_status hs_axpby(int32_t in_dtype, int32_t out_dtype, const void* x, const voi
 hs_status hs_dropout(int32_t dtype, const void* x, void* out, int64_t n, float p, uint64_t seed, void* stream);
 hs_status hs_relu_fwd(int32_t dtype, const void* x, void* out, int64_t n, void* stream);
 hs_status hs_relu_bwd(int32_t dtype, const void* dy, const void* y, void* dx, int64_t n, void* stream);
+/* dx = dy * gelu'(u)  (erf GELU). */
+hs_status hs_gelu_bwd(int32_t dtype, const void* dy, const void* u, void* dx, int64_t n, void* stream);
+/* out = x * scalar[0] with the scalar on the device (loss backward without a host sync). */
+hs_status hs_mul_dev_scalar(const float* x, const float* scalar, float* out, int64_t n, void* stream);
 /* out[n] (+)= sum_m x[m*ld + n]  (bias gradients). */
 hs_status hs_colsum(int32_t dtype, const void* x, int64_t M, int32_t N, int32_t ld, float* out, void* ws,
                     int64_t ws_bytes, int32_t accumulate, void* stream);
@@ -222,9 +226,10 @@ hs_status hs_bert_embed_fwd(int32_t dtype, const int64_t* ids, const float* word
                             const float* gamma, const float* beta, void* sum_out, void* y, float* mean, float* rstd,
                             int64_t tokens, int32_t L, int32_t H, int32_t V, float eps, float dropout_p, uint64_t seed,
                             void* stream);
-/* dword (zero-filled by the caller) += scatter(dsum by ids); dpos[l] = sum_b dsum[b][l]. */
+/* dword (zero-filled by the caller) += scatter(dsum by ids), skipping ids == pad_id (nn.Embedding
+   padding_idx; -1 = none); dpos[l] = sum_b dsum[b][l]. */
 hs_status hs_bert_embed_bwd(int32_t dtype, const int64_t* ids, const void* dsum, float* dword, float* dpos, int32_t B,
-                            int32_t L, int32_t H, int32_t V, void* stream);
+                            int32_t L, int32_t H, int32_t V, int32_t pad_id, void* stream);
 /* mean-reduced CrossEntropyLoss(weight, label_smoothing): writes the scalar loss, d loss / d logits
    (optional) and the per-row unreduced losses (optional). reference scripts/train.py:240,252-254. */
 hs_status hs_cross_entropy(const float* logits, const int64_t* labels, const float* weight, float label_smoothing,
@@ -233,6 +238,41 @@ hs_status hs_cross_entropy(const float* logits, const int64_t* labels, const flo
 hs_status hs_adam_step_multi(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
                              float* const* exp_avg_sq, const int64_t* n, float lr, float beta1, float beta2, float eps,
                              float weight_decay, int32_t step, int32_t decoupled, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------- */
+/* small f32 operators at the fusion / head / loss boundary                                       */
+/* ------------------------------------------------------------------------------------------- */
+/* out[b][:] = x[b][t][:] as f32 (CLS pooling, reference modules/fusion_blocks.py:170-173). */
+hs_status hs_select_token_fwd(int32_t dtype, const void* x, float* out, int32_t B, int32_t Nt, int32_t H, int32_t t,
+                              void* stream);
+hs_status hs_select_token_bwd(int32_t dtype, const float* dy, void* dx, int32_t B, int32_t Nt, int32_t H, int32_t t,
+                              void* stream);
+/* out[r] = [a[r] | b[r]] and its inverse (torch.cat(dim=1): fusion_blocks.py:186, model_resnet.py:59). */
+hs_status hs_concat2(const float* a, int32_t Ha, const float* b, int32_t Hb, float* out, int64_t rows, void* stream);
+hs_status hs_split2(const float* g, float* da, int32_t Ha, float* db, int32_t Hb, int64_t rows, void* stream);
+/* out = a*b; b_mode 0: same shape, 1: b is (rows,1), 2: b is a scalar. */
+hs_status hs_mul(const float* a, const float* b, float* out, int64_t rows, int32_t cols, int32_t b_mode, void* stream);
+hs_status hs_rowdot(const float* a, const float* b, float* out, int32_t rows, int32_t cols, void* stream);
+/* out[0] = sum a[i]*b[i] (b NULL: sum a). */
+hs_status hs_dot(const float* a, const float* b, float* out, int64_t n, void* stream);
+hs_status hs_sigmoid_fwd(const float* x, float* out, int64_t n, void* stream);
+hs_status hs_sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+/* ent[r] = -sum softmax(z)*log(softmax(z)+1e-8); with g/dlogits set it also writes the backward
+   (reference model.py:276-278). */
+hs_status hs_softmax_entropy(const float* logits, const float* g, float* ent, float* dlogits, int32_t rows, int32_t C,
+                             void* stream);
+/* MIBF MP-Loss: 0.3 CE(img) + 0.6 CE(txt) + 1.1 mean(exp(symKL)) CE(fused), loss + three logit gradients
+   (reference mibf_net/model_resnet.py:76-94). scratch: B floats. */
+hs_status hs_mp_loss(const float* image_logits, const float* text_logits, const float* fused_logits, const int64_t* labels,
+                     int32_t B, int32_t C, float* loss, float* d_image, float* d_text, float* d_fused, float* scratch,
+                     void* stream);
+/* FocalLoss(gamma, weight), mean reduction (reference scripts/train.py:46-61). */
+hs_status hs_focal_loss(const float* logits, const int64_t* labels, const float* weight, float gamma, int32_t B, int32_t C,
+                        float* loss, float* dlogits, void* stream);
+/* out = bilinear_resize(x[:, :, y0:y0+ch, x0:x0+cw], (H, W)), align_corners=False, f32 NCHW
+   (reference model.py:292-301). */
+hs_status hs_center_crop_resize(const float* x, float* out, int32_t N, int32_t Cc, int32_t H, int32_t W, int32_t y0,
+                                int32_t x0, int32_t ch, int32_t cw, void* stream);
 
 /* ------------------------------------------------------------------------------------------- */
 /* Composite executors: one call = one nn.Module forward (or backward) of the reference's module  */

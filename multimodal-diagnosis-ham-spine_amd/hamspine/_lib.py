@@ -6,9 +6,11 @@ used by tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke().)
 """
 import ctypes as C
 import os
+import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhamspine_hip.so")
+HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "hamspine.h"))
 
 HS_OK = 0
 HS_F32, HS_BF16 = 0, 1
@@ -16,6 +18,9 @@ A_KC, A_RC, A_CONV, A_DGRAD = 0, 1, 2, 3
 B_KC, B_RC, B_WDGRAD, B_CONV = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 MUL_NONE, MUL_GELU_GRAD, MUL_RELU_MASK = 0, 1, 2
+CAST_MAX, ADAM_MAX = 48, 32
+
+i32, i64, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
 
 
 class HamspineError(RuntimeError):
@@ -23,29 +28,97 @@ class HamspineError(RuntimeError):
 
 
 class ConvGeom(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in (
+    _fields_ = [(n, i32) for n in (
         "N", "H", "W", "C", "P", "Q", "K", "R", "S", "stride", "pad",
         "row_pitch", "img_pitch", "qstep", "no_bounds")]
 
 
 class GemmParams(C.Structure):
     _fields_ = [
-        ("dtype", C.c_int32), ("a_kind", C.c_int32), ("b_kind", C.c_int32),
-        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
-        ("A", C.c_void_p), ("B", C.c_void_p),
-        ("a_elems", C.c_int64), ("b_elems", C.c_int64),
-        ("lda", C.c_int32), ("ldb", C.c_int32),
+        ("dtype", i32), ("a_kind", i32), ("b_kind", i32),
+        ("M", i32), ("N", i32), ("K", i32),
+        ("A", vp), ("B", vp),
+        ("a_elems", i64), ("b_elems", i64),
+        ("lda", i32), ("ldb", i32),
         ("g", ConvGeom),
-        ("batch", C.c_int32), ("batch_inner", C.c_int32),
-        ("a_bs0", C.c_int64), ("a_bs1", C.c_int64), ("b_bs0", C.c_int64), ("b_bs1", C.c_int64),
-        ("d_bs0", C.c_int64), ("d_bs1", C.c_int64),
-        ("split_k", C.c_int32), ("splitk_ws", C.c_void_p),
-        ("D", C.c_void_p), ("ldd", C.c_int32), ("out_dtype", C.c_int32),
-        ("alpha", C.c_float), ("bias", C.c_void_p), ("act", C.c_int32),
-        ("D_preact", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int32),
-        ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
-        ("mul_mode", C.c_int32), ("mul_src", C.c_void_p), ("ldm", C.c_int32),
-        ("accumulate", C.c_int32),
+        ("batch", i32), ("batch_inner", i32),
+        ("a_bs0", i64), ("a_bs1", i64), ("b_bs0", i64), ("b_bs1", i64),
+        ("d_bs0", i64), ("d_bs1", i64),
+        ("split_k", i32), ("splitk_ws", vp),
+        ("D", vp), ("ldd", i32), ("out_dtype", i32),
+        ("alpha", f32), ("bias", vp), ("act", i32),
+        ("D_preact", vp), ("residual", vp), ("ldr", i32),
+        ("dropout_p", f32), ("dropout_seed", u64),
+        ("mul_mode", i32), ("mul_src", vp), ("ldm", i32),
+        ("accumulate", i32),
+    ]
+
+
+class BnParams(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("C", i32), ("M", i64), ("training", i32), ("relu", i32),
+        ("eps", f32), ("momentum", f32),
+        ("x", vp), ("residual", vp), ("y", vp), ("gamma", vp), ("beta", vp),
+        ("running_mean", vp), ("running_var", vp), ("save_mean", vp), ("save_invstd", vp),
+        ("scale", vp), ("shift", vp), ("ws", vp), ("ws_bytes", i64),
+    ]
+
+
+class BnBwdParams(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("C", i32), ("M", i64), ("training", i32), ("relu", i32),
+        ("dy", vp), ("y", vp), ("x", vp), ("gamma", vp), ("save_mean", vp), ("save_invstd", vp),
+        ("dx", vp), ("dres", vp), ("dgamma", vp), ("dbeta", vp), ("ws", vp), ("ws_bytes", i64),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("B", i32), ("H", i32), ("Lq", i32), ("Lk", i32), ("hd", i32),
+        ("q_bs", i64), ("k_bs", i64), ("v_bs", i64), ("o_bs", i64),
+        ("q_ld", i32), ("k_ld", i32), ("v_ld", i32), ("o_ld", i32),
+        ("scale", f32), ("dropout_p", f32), ("seed", u64), ("key_mask", vp),
+    ]
+
+
+class ConvBn(C.Structure):
+    _fields_ = [
+        ("Cin", i32), ("Cout", i32), ("R", i32), ("stride", i32), ("pad", i32),
+        ("w", vp), ("gamma", vp), ("beta", vp), ("running_mean", vp), ("running_var", vp),
+        ("dw", vp), ("dgamma", vp), ("dbeta", vp),
+    ]
+
+
+class ResblockDesc(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("N", i32), ("H", i32), ("W", i32), ("training", i32),
+        ("eps", f32), ("momentum", f32), ("n_main", i32), ("main", ConvBn * 3),
+        ("has_ds", i32), ("ds", ConvBn),
+    ]
+
+
+class StemDesc(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("N", i32), ("H", i32), ("W", i32), ("training", i32),
+        ("eps", f32), ("momentum", f32), ("cb", ConvBn),
+    ]
+
+
+class Linear(C.Structure):
+    _fields_ = [("in_f", i32), ("out_f", i32), ("w", vp), ("b", vp), ("dw", vp), ("db", vp)]
+
+
+class Norm(C.Structure):
+    _fields_ = [("gamma", vp), ("beta", vp), ("dgamma", vp), ("dbeta", vp)]
+
+
+class BertLayerDesc(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("B", i32), ("L", i32), ("hidden", i32), ("heads", i32), ("inter", i32),
+        ("ln_eps", f32), ("hidden_dropout", f32), ("attn_dropout", f32), ("seed", u64),
+        ("attention_mask", vp),
+        ("q", Linear), ("k", Linear), ("v", Linear), ("ao", Linear), ("ln1", Norm),
+        ("inter_l", Linear), ("out_l", Linear), ("ln2", Norm),
     ]
 
 
@@ -61,16 +134,64 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
         _lib = C.CDLL(LIB_PATH)
-        _lib.hs_last_error.restype = C.c_char_p
-        _lib.hs_gemm_splitk_ws_bytes.restype = C.c_int64
         _declare(_lib)
     return _lib
 
 
 def _declare(l):
-    l.hs_gemm.argtypes = [C.POINTER(GemmParams), C.c_void_p]
-    l.hs_gemm_splitk_ws_bytes.argtypes = [C.POINTER(GemmParams)]
-    l.hs_gemm_suggest_split.argtypes = [C.c_int32] * 4
+    P = C.POINTER
+    l.hs_last_error.restype = C.c_char_p
+    l.hs_gemm.argtypes = [P(GemmParams), vp]
+    l.hs_gemm_splitk_ws_bytes.argtypes = [P(GemmParams)]
+    l.hs_gemm_splitk_ws_bytes.restype = i64
+    l.hs_gemm_suggest_split.argtypes = [i32] * 4
+    l.hs_batchnorm_fwd.argtypes = [P(BnParams), vp]
+    l.hs_batchnorm_bwd.argtypes = [P(BnBwdParams), vp]
+    l.hs_batchnorm_ws_bytes.argtypes = [i64, i32, i32]
+    l.hs_batchnorm_ws_bytes.restype = i64
+    l.hs_layernorm_fwd.argtypes = [i32, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp]
+    l.hs_layernorm_bwd.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, vp]
+    l.hs_layernorm_bwd_ws_bytes.argtypes = [i64, i32]
+    l.hs_layernorm_bwd_ws_bytes.restype = i64
+    l.hs_maxpool_fwd.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    l.hs_maxpool_bwd.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    l.hs_mean_tokens_fwd.argtypes = [i32, vp, vp, i32, i32, i32, i32, vp]
+    l.hs_mean_tokens_bwd.argtypes = [i32, vp, vp, i32, i32, i32, i32, vp]
+    l.hs_pack_image.argtypes = [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    l.hs_pack_stem_weight.argtypes = [i32, vp, vp, i32, i32, i32, i32, vp]
+    l.hs_unpack_stem_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    l.hs_cast_f32_to_bf16_multi.argtypes = [i32, P(vp), P(vp), P(i64), vp]
+    l.hs_axpby.argtypes = [i32, i32, vp, vp, vp, i64, f32, f32, vp]
+    l.hs_dropout.argtypes = [i32, vp, vp, i64, f32, u64, vp]
+    l.hs_relu_fwd.argtypes = [i32, vp, vp, i64, vp]
+    l.hs_relu_bwd.argtypes = [i32, vp, vp, vp, i64, vp]
+    l.hs_gelu_bwd.argtypes = [i32, vp, vp, vp, i64, vp]
+    l.hs_mul_dev_scalar.argtypes = [vp, vp, vp, i64, vp]
+    l.hs_colsum.argtypes = [i32, vp, i64, i32, i32, vp, vp, i64, i32, vp]
+    l.hs_colsum_ws_bytes.argtypes = [i64, i32]
+    l.hs_colsum_ws_bytes.restype = i64
+    l.hs_softmax_fwd.argtypes = [i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, u64, vp]
+    l.hs_softmax_bwd.argtypes = [i32, vp, vp, vp, i64, i32, i32, i32, f32, u64, vp]
+    l.hs_bert_embed_fwd.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, f32, f32, u64, vp]
+    l.hs_bert_embed_bwd.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    l.hs_cross_entropy.argtypes = [vp, vp, vp, f32, i32, i32, vp, vp, vp, vp]
+    l.hs_adam_step_multi.argtypes = [i32, P(vp), P(vp), P(vp), P(vp), P(i64), f32, f32, f32, f32, f32, i32, i32, f32, vp]
+    l.hs_attention_query.argtypes = [P(AttnDesc), P(i64), P(i64)]
+    l.hs_attention_fwd.argtypes = [P(AttnDesc), vp, vp, vp, vp, vp, i64, vp, i64, vp]
+    l.hs_attention_bwd.argtypes = [P(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp]
+    l.hs_resblock_query.argtypes = [P(ResblockDesc), P(i64), P(i64)]
+    l.hs_resblock_fwd.argtypes = [P(ResblockDesc), vp, vp, vp, i64, vp, i64, vp]
+    l.hs_resblock_bwd.argtypes = [P(ResblockDesc), vp, vp, vp, vp, vp, i64, vp, i64, vp]
+    l.hs_stem_query.argtypes = [P(StemDesc), P(i64), P(i64)]
+    l.hs_stem_fwd.argtypes = [P(StemDesc), vp, vp, vp, i64, vp, i64, vp]
+    l.hs_stem_bwd.argtypes = [P(StemDesc), vp, vp, vp, i64, vp, i64, vp]
+    l.hs_bert_layer_query.argtypes = [P(BertLayerDesc), P(i64), P(i64)]
+    l.hs_bert_layer_fwd.argtypes = [P(BertLayerDesc), vp, vp, vp, i64, vp, i64, vp]
+    l.hs_bert_layer_bwd.argtypes = [P(BertLayerDesc), vp, vp, vp, vp, i64, vp, i64, vp]
+    l.hs_linear_fwd.argtypes = [i32, vp, i64, i32, P(Linear), vp, vp, i32, i32, i32, vp, vp, i32, f32, u64, vp]
+    l.hs_linear_bwd.argtypes = [i32, vp, i64, i32, P(Linear), vp, vp, i32, vp, i32, i32, i32, vp, i32, vp, vp, i64, vp]
+    l.hs_linear_bwd_ws_bytes.argtypes = [i64, i32, i32, i32]
+    l.hs_linear_bwd_ws_bytes.restype = i64
 
 
 def check(status, what=""):
@@ -81,8 +202,6 @@ def check(status, what=""):
 
 def exported_symbols():
     """Names declared in include/hamspine.h (used by the CPU-side ABI test)."""
-    import re
-    hdr = os.path.join(_HERE, "..", "..", "include", "hamspine.h")
-    txt = open(hdr).read()
+    txt = open(HEADER_PATH).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(hs_[a-z0-9_]+)\s*\(", txt)))

@@ -251,6 +251,20 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ dy,
         o[i] = to_f32(y[i]) > 0.f ? dy[i] : from_f32<T>(0.f);
 }
 
+// dx = dy * gelu'(u)
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ u,
+                                                       T* __restrict__ o, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        o[i] = from_f32<T>(to_f32(dy[i]) * gelu_erf_grad(to_f32(u[i])));
+}
+// out = x * (*scalar)   (scalar lives on the device: no host sync in loss backward)
+__global__ __launch_bounds__(256) void mul_dev_scalar_kernel(const float* __restrict__ x, const float* __restrict__ sc,
+                                                             float* __restrict__ o, long long n) {
+    const float s = sc[0];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) o[i] = x[i] * s;
+}
+
 // ============================================================================================
 // column sum: X [M][N] -> out[N] (f32), used for bias gradients.  Deterministic two-stage.
 // ============================================================================================
@@ -426,7 +440,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
 // scatter-add of token gradients into the word table (atomics: duplicates of an id collide)
 template <typename T>
 __global__ __launch_bounds__(256) void embed_word_bwd_kernel(const long long* __restrict__ ids, const T* __restrict__ dsum,
-                                                             float* __restrict__ dword, long long tokens, int H, int V) {
+                                                             float* __restrict__ dword, long long tokens, int H, int V,
+                                                             int pad_id) {
     const long long total = tokens * H;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long t = i / H;
@@ -434,6 +449,7 @@ __global__ __launch_bounds__(256) void embed_word_bwd_kernel(const long long* __
         long long id = ids[t];
         if (id < 0) id = 0;
         if (id >= V) id = V - 1;
+        if (id == pad_id) continue;   // nn.Embedding(padding_idx): the pad row receives no gradient
         atomicAdd(dword + id * H + h, to_f32(dsum[i]));
     }
 }
@@ -769,6 +785,23 @@ hs_status hs_relu_bwd(int32_t dtype, const void* dy, const void* y, void* dx, in
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
+hs_status hs_gelu_bwd(int32_t dtype, const void* dy, const void* u, void* dx, int64_t n, void* stream) {
+    HS_REQUIRE(dy && u && dx, "gelu_bwd: null argument");
+    if (dtype == HS_BF16)
+        hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                           (const bf16_t*)u, (bf16_t*)dx, n);
+    else
+        hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
+                           (const float*)u, (float*)dx, n);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_mul_dev_scalar(const float* x, const float* scalar, float* out, int64_t n, void* stream) {
+    HS_REQUIRE(x && scalar && out, "mul_dev_scalar: null argument");
+    hipLaunchKernelGGL(mul_dev_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, scalar, out, n);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
 hs_status hs_colsum(int32_t dtype, const void* x, int64_t M, int32_t N, int32_t ld, float* out, void* ws,
                     int64_t ws_bytes, int32_t accumulate, void* stream) {
     HS_REQUIRE(x && out && M > 0 && N > 0, "colsum: bad argument");
@@ -808,17 +841,17 @@ hs_status hs_bert_embed_fwd(int32_t dtype, const int64_t* ids, const float* word
     return HS_OK;
 }
 hs_status hs_bert_embed_bwd(int32_t dtype, const int64_t* ids, const void* dsum, float* dword, float* dpos, int32_t B,
-                            int32_t L, int32_t H, int32_t V, void* stream) {
+                            int32_t L, int32_t H, int32_t V, int32_t pad_id, void* stream) {
     HS_REQUIRE(ids && dsum, "bert_embed_bwd: null argument");
     hipStream_t s = (hipStream_t)stream;
     const long long tokens = (long long)B * L;
     if (dword) {   // caller zero-fills dword first
         if (dtype == HS_BF16)
             hipLaunchKernelGGL(embed_word_bwd_kernel<bf16_t>, dim3(grid_for(tokens * H)), dim3(256), 0, s,
-                               (const long long*)ids, (const bf16_t*)dsum, dword, tokens, H, V);
+                               (const long long*)ids, (const bf16_t*)dsum, dword, tokens, H, V, pad_id);
         else
             hipLaunchKernelGGL(embed_word_bwd_kernel<float>, dim3(grid_for(tokens * H)), dim3(256), 0, s,
-                               (const long long*)ids, (const float*)dsum, dword, tokens, H, V);
+                               (const long long*)ids, (const float*)dsum, dword, tokens, H, V, pad_id);
         HS_LAUNCH_CHECK();
     }
     if (dpos) {

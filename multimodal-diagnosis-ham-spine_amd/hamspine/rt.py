@@ -1,0 +1,94 @@
+"""Runtime plumbing shared by the autograd functions: scratch arenas, dropout seeds, pointer helpers."""
+import ctypes as C
+import threading
+
+import torch
+
+from . import _lib as L
+
+_tls = threading.local()
+_ws = {}
+_seed_lock = threading.Lock()
+_seed_state = {"base": None, "ctr": 0}
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def workspace(nbytes, device):
+    """One growing scratch buffer per (device, thread).  All kernels of one thread are ordered on the
+    current stream, so reuse between consecutive calls is safe; the autograd engine thread gets its
+    own buffer so a forward running ahead on the main thread never shares scratch with a backward."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), threading.get_ident())
+    t = _ws.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = t
+    return t
+
+
+def next_seed():
+    """Dropout seeds: a counter offset by torch's seed, so torch.manual_seed makes runs repeatable."""
+    with _seed_lock:
+        if _seed_state["base"] is None:
+            _seed_state["base"] = (torch.initial_seed() * 0x9E3779B1) & 0xFFFFFFFFFFFF
+        _seed_state["ctr"] += 1
+        return (_seed_state["base"] + _seed_state["ctr"] * 16) & 0xFFFFFFFFFFFFFFF
+
+
+def reset_seed(base=None):
+    with _seed_lock:
+        _seed_state["base"] = base
+        _seed_state["ctr"] = 0
+
+
+def hs_dtype(t_or_dtype):
+    dt = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    if dt == torch.bfloat16:
+        return L.HS_BF16
+    if dt == torch.float32:
+        return L.HS_F32
+    raise L.HamspineError(f"unsupported dtype {dt}")
+
+
+def need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise L.HamspineError(
+                f"hamspine kernels only run on the HIP device (got a tensor on {t.device}); there is no CPU fallback")
+
+
+def p(t, byte_offset=0):
+    """raw device pointer (int) of a tensor, or None."""
+    if t is None:
+        return None
+    return t.data_ptr() + byte_offset
+
+
+def query(fn, desc):
+    sv, ws = C.c_int64(0), C.c_int64(0)
+    L.check(fn(C.byref(desc), C.byref(sv), C.byref(ws)), fn.__name__)
+    return sv.value, ws.value
+
+
+def as_cl(t, dtype):
+    """NCHW-shaped tensor with NHWC memory of the compute dtype (no copy when it already is)."""
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def empty_cl(shape, dtype, device):
+    return torch.empty(shape, dtype=dtype, device=device, memory_format=torch.channels_last)
+
+
+def cast_weights(tensors, device):
+    """f32 parameter tensors -> bf16 copies in one launch (memory order preserved)."""
+    outs = [torch.empty(t.numel(), dtype=torch.bfloat16, device=device) for t in tensors]
+    n = len(tensors)
+    src = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    dst = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+    cnt = (C.c_int64 * n)(*[t.numel() for t in tensors])
+    L.check(L.lib().hs_cast_f32_to_bf16_multi(n, src, dst, cnt, stream()), "hs_cast_f32_to_bf16_multi")
+    return outs

@@ -1,0 +1,243 @@
+"""ORACLE -- test infrastructure only.  Generates tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Run here (the reference tree is not shipped to the GPU box; only the .npz vectors travel):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+What is executed from /root/reference (read-only, imported, never copied):
+  modules.fusion_blocks / modules.heads / modules.gating / modules.tabular, mibf_net.attention,
+  mibf_net.bert (with a locally saved tiny transformers BertModel), and -- through a stand-in
+  `torchvision.models` that maps resnet18/34/50 to oracle.towers.oresnet -- the reference's own
+  model.py / encoder.py / mibf_net/model_resnet.py forward, cal_loss and autograd backward.
+The stand-in only replaces the third-party tower the container lacks; every line of
+glue that produces the vectors is the reference's.
+
+Every vector is a function of (case name, seed): weights come from oracle.procedural, so a fixture holds
+inputs, outputs and gradients only.
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+
+from oracle import towers  # noqa: E402
+from oracle.procedural import load_procedural, synthetic_batch  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+SEED = 20260
+TINY_BERT = dict(vocab_size=120, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                 max_position_embeddings=40, type_vocab_size=2, hidden_dropout_prob=0.0,
+                 attention_probs_dropout_prob=0.0)
+MIBF_BERT = dict(vocab_size=200, hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=256,
+                 max_position_embeddings=40, type_vocab_size=2, hidden_dropout_prob=0.0,
+                 attention_probs_dropout_prob=0.0)
+
+
+def install_torchvision_standin():
+    tv = types.ModuleType("torchvision")
+    models = types.ModuleType("torchvision.models")
+
+    def builder(name):
+        def build(weights=None, pretrained=False, **kw):   # weights / pretrained accepted and ignored: no fetch
+            return towers.oresnet(name)
+        return build
+    for n in ("resnet18", "resnet34", "resnet50"):
+        setattr(models, n, builder(n))
+    for n in ("ResNet18_Weights", "ResNet34_Weights", "ResNet50_Weights"):
+        setattr(models, n, types.SimpleNamespace(IMAGENET1K_V1=None, DEFAULT=None))
+    tv.models = models
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = models
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    flat = {}
+    for k, v in arrays.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                flat[f"{k}::{kk}"] = vv.detach().cpu().numpy() if torch.is_tensor(vv) else np.asarray(vv)
+        else:
+            flat[k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **flat)
+    print(f"wrote {name}.npz ({sum(a.size for a in flat.values())} values)")
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def run_case(name, module, inputs, seed, train=True, out_fn=None):
+    """seeded weights -> forward -> sum(out * cotangent) -> backward; stores out, input grads, param grads"""
+    load_procedural(module, seed)
+    module.train(train)
+    leaves = {k: v.clone().requires_grad_(True) if torch.is_tensor(v) and v.is_floating_point() else v
+              for k, v in inputs.items()}
+    out = out_fn(module, leaves) if out_fn else module(**leaves)
+    cot = rnd(tuple(out.shape), seed + 1)
+    (out * cot).sum().backward()
+    gin = {k: v.grad for k, v in leaves.items() if torch.is_tensor(v) and v.is_floating_point() and v.grad is not None}
+    gw = {k: p.grad for k, p in module.named_parameters() if p.grad is not None}
+    save(name, out=out, cot=cot, inp={k: v for k, v in inputs.items() if torch.is_tensor(v)}, gin=gin, gw=gw)
+
+
+def gen_fusion():
+    from modules import fusion_blocks as fb
+    B, N, H, T, Lk, heads = 4, 10, 64, 96, 16, 4
+    lens = torch.tensor([16, 9, 5, 2])
+    mask = (torch.arange(Lk)[None] < lens[:, None]).long()
+    img, txt = rnd((B, N, H), 11), rnd((B, Lk, T), 12)
+
+    def call3(m, l):
+        return m(l["img"], l["txt"], l["mask"])
+    run_case("fusion_basic", fb.FusionModule(T, H, heads, 0.0), dict(img=img, txt=txt, mask=mask), SEED + 1, out_fn=call3)
+    run_case("fusion_crossblock", fb.CrossAttentionBlock(T, H, heads, 0.0), dict(img=img, txt=txt, mask=mask), SEED + 2,
+             out_fn=call3)
+    ms = {"layer2": rnd((B, 36, H), 21), "layer3": rnd((B, 16, H), 22), "layer4": rnd((B, 4, H), 23)}
+
+    def call_ms(m, l):
+        return m({k: l[k] for k in ("layer2", "layer3", "layer4")}, l["txt"], l["mask"])
+    run_case("fusion_multiscale", fb.MultiScaleFusionModule(T, H, heads, 0.0), dict(txt=txt, mask=mask, **ms), SEED + 3,
+             out_fn=call_ms)
+    kinds = {"concat": fb.ConcatFusionModule, "weighted_concat": fb.WeightedConcatFusionModule,
+             "hadamard": fb.HadamardFusionModule, "bilinear": fb.BilinearFusionModule}
+    i = 0
+    for kn, cls in kinds.items():
+        for pool in ("cls", "mean"):
+            i += 1
+            run_case(f"fusion_{kn}_{pool}_tensor", cls(T, H, text_pool=pool), dict(img=img, txt=txt, mask=mask),
+                     SEED + 10 + i, out_fn=call3)
+            run_case(f"fusion_{kn}_{pool}_dict", cls(T, H, text_pool=pool), dict(txt=txt, mask=mask, **ms),
+                     SEED + 30 + i, out_fn=call_ms)
+
+
+def gen_heads():
+    from modules import gating, heads, tabular
+    B, H, Cn = 6, 64, 7
+    x = rnd((B, H), 31)
+    run_case("head_residual", heads.ResidualClassifier(H, H, Cn, 0.0), dict(x=x), SEED + 50)
+    run_case("head_attnpool", heads.AttentionPoolingClassifier(H, H, Cn, 4, 0.0), dict(x=x), SEED + 51)
+    ent = rnd((B, 1), 33).abs()
+    run_case("gate_entropy", gating.DualExpertGate(H, H, 32, True), dict(lesion_feat=x, context_feat=rnd((B, H), 32),
+                                                                        entropy=ent), SEED + 52)
+    run_case("gate_plain", gating.DualExpertGate(H, H, 32, False), dict(lesion_feat=x, context_feat=rnd((B, H), 32)),
+             SEED + 53)
+    run_case("tabular", tabular.TabularEncoder(11, 32, 0.0), dict(x=rnd((B, 11), 34)), SEED + 54)
+
+
+def gen_ibfa():
+    from mibf_net import attention as att
+    B, D = 5, 64
+    x, y = rnd((B, 1, D), 41), rnd((B, 1, D), 42)
+    run_case("ibfa_h1", att.MultiHeadCrossAttention_v2(D, 1), dict(x=x, y=y), SEED + 60)
+    run_case("ibfa_h4", att.MultiHeadCrossAttention_v2(D, 4), dict(x=x, y=y), SEED + 61)
+    p = torch.softmax(rnd((B, 6), 43), -1)
+    q = torch.softmax(rnd((B, 6), 44), -1)
+    q[0, 0] = 0.0   # exercises the 1e-8 clamp
+    save("kl_divergence", p=p, q=q, kl=att.compute_kl_divergence(p, q))
+
+
+def save_tiny_bert(cfg, tmp):
+    from transformers import BertConfig, BertModel
+    d = os.path.join(tmp, f"bert_{cfg['hidden_size']}_{cfg['num_hidden_layers']}")
+    BertModel(BertConfig(**cfg)).save_pretrained(d)
+    return d
+
+
+def gen_bert(tmp):
+    from mibf_net.bert import BertEncoder
+    d = save_tiny_bert(TINY_BERT, tmp)
+    enc = BertEncoder(model_path=d)
+    load_procedural(enc, SEED + 70)
+    enc.train()
+    _, ids, mask, _ = synthetic_batch(4, 8, 24, TINY_BERT["vocab_size"], 7, seed=71, min_len=3)
+    cls = enc(ids, mask)
+    hidden = enc.bert(input_ids=ids, attention_mask=mask).last_hidden_state
+    cot = rnd(tuple(hidden.shape), 72)
+    (hidden * cot).sum().backward()
+    gw = {k: p.grad for k, p in enc.named_parameters() if p.grad is not None}
+    save("bert_tiny", ids=ids, mask=mask, cls=cls, hidden=hidden, cot=cot, gw=gw)
+
+
+def e2e_store(name, model, logits, loss, extra=None):
+    loss.backward()
+    norms = {k: p.grad.norm() for k, p in model.named_parameters() if p.grad is not None}
+    small = {k: p.grad for k, p in model.named_parameters() if p.grad is not None and p.numel() <= 20000}
+    none_grad = sorted(k for k, p in model.named_parameters() if p.grad is None)
+    save(name, logits=logits, loss=loss, gnorm=norms, gw=small, nograd=np.array(none_grad), **(extra or {}))
+
+
+def gen_e2e_baseline(tmp):
+    import model as ref_model
+    d = save_tiny_bert(TINY_BERT, tmp)
+    images, ids, mask, labels = synthetic_batch(4, 64, 24, TINY_BERT["vocab_size"], 7, seed=81, min_len=3)
+    tab = rnd((4, 9), 82)
+    common = dict(num_classes=7, text_feature_dim=64, hidden_dim=64, dropout=0.0, pretrained_image=False,
+                  image_weights_path=None, text_model_name=d, num_heads=4, image_backbone="resnet18")
+    cases = {
+        "e2e_basic_mlp": dict(fusion_type="basic", classifier_type="mlp"),
+        "e2e_multiscale_residual": dict(fusion_type="multiscale", classifier_type="residual"),
+        "e2e_concat_tabular": dict(fusion_type="concat", classifier_type="mlp", tabular_enabled=True, tabular_input_dim=9,
+                                   tabular_hidden_dim=32, tabular_dropout=0.0),
+        "e2e_bilinear_attnpool": dict(fusion_type="bilinear", classifier_type="attention_pooling", text_pool="mean"),
+        "e2e_gate_globallocal": dict(fusion_type="basic", classifier_type="mlp", gate_enabled=True, gate_hidden_dim=32,
+                                     global_local_enabled=True, global_local_crop_ratio=0.6),
+        "e2e_hadamard_imageonly": dict(fusion_type="hadamard", classifier_type="mlp"),
+    }
+    crit = torch.nn.CrossEntropyLoss(label_smoothing=0.02)
+    for i, (name, kw) in enumerate(cases.items()):
+        m = ref_model.MultimodalBaselineModel(**common, **kw)
+        load_procedural(m, SEED + 100 + i)
+        m.train()
+        t = tab if kw.get("tabular_enabled") else None
+        if name == "e2e_hadamard_imageonly":
+            logits = m(images, ids, mask, tabular_input=t, ablation_mode="image_only")
+        elif kw.get("gate_enabled"):
+            logits = m(images, ids, mask, tabular_input=t)
+        else:   # the training script calls forward_features + classifier separately (scripts/train.py:373-380)
+            logits = m.classifier(m.forward_features(images, ids, mask, tabular_input=t))
+        e2e_store(name, m, logits, crit(logits, labels))
+        # eval-mode logits (running statistics) for the inference path
+        m.eval()
+        with torch.no_grad():
+            ev = m(images, ids, mask, tabular_input=t)
+        np.savez_compressed(os.path.join(OUT, name + "_eval.npz"), logits=ev.numpy())
+
+
+def gen_e2e_mibf(tmp):
+    from mibf_net import model_resnet as mr
+    d = save_tiny_bert(MIBF_BERT, tmp)
+    images, ids, mask, labels = synthetic_batch(4, 64, 16, MIBF_BERT["vocab_size"], 6, seed=91, min_len=3)
+    for j, lc in enumerate(("KL_loss", "text_image_textimage_loss")):
+        m = mr.Resnet50WithOurs(num_labels=6, loss_class=lc, bert_path=d)
+        load_procedural(m, SEED + 200)
+        m.train()
+        out = m({"input_ids": ids, "attention_mask": mask, "transformed_image": images})
+        loss = m.cal_loss(out, labels)
+        e2e_store(f"e2e_mibf_{lc}", m, out["image_text"], loss, extra=dict(text=out["text"], image=out["image"]))
+
+
+def main():
+    torch.set_num_threads(8)
+    from transformers import BertConfig, BertModel  # noqa: F401  (import before the stand-in exists: transformers probes torchvision)
+    install_torchvision_standin()
+    sys.path.insert(0, REF)
+    with tempfile.TemporaryDirectory() as tmp:
+        gen_fusion()
+        gen_heads()
+        gen_ibfa()
+        gen_bert(tmp)
+        gen_e2e_baseline(tmp)
+        gen_e2e_mibf(tmp)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,196 @@
+"""CPU suite (no GPU): pins the oracle against the golden vectors that were produced by running the
+reference (oracle/gen_golden.py), against the installed transformers BertModel, and against the
+known-answer facts of SURVEY.md Appendix B; checks the C ABI surface and the product's module trees."""
+import os
+
+import pytest
+import torch
+
+import golden_cases as gc
+from oracle import models as om
+from oracle import towers
+from oracle.procedural import load_procedural
+
+TOL = dict(rtol=2e-5, atol=2e-6)
+
+
+def _close(a, b, what, rtol=2e-5, atol=2e-6):
+    scale = max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item()
+    assert err <= rtol * scale + atol, f"{what}: max err {err:.3e} (scale {scale:.3e})"
+
+
+@pytest.mark.parametrize("name", sorted(gc.MODULE_CASES))
+def test_oracle_module_matches_reference_vectors(name):
+    seed, ofac, _, caller = gc.MODULE_CASES[name]
+    fx = gc.load(name)
+    m = load_procedural(ofac(), seed).train()
+    inp = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in fx["inp"].items()}
+    out = caller(m, inp)
+    _close(out, fx["out"], f"{name}: out")
+    (out * fx["cot"]).sum().backward()
+    for k, g in fx.get("gin", {}).items():
+        _close(inp[k].grad, g, f"{name}: d/d{k}", rtol=1e-4)
+    params = dict(m.named_parameters())
+    assert set(fx["gw"]) <= set(params), f"{name}: key mismatch {set(fx['gw']) - set(params)}"
+    for k, g in fx["gw"].items():
+        _close(params[k].grad, g, f"{name}: grad {k}", rtol=1e-4)
+
+
+def test_kl_divergence_vector():
+    fx = gc.load("kl_divergence")
+    _close(om.okl(fx["p"], fx["q"]), fx["kl"], "kl")
+
+
+def test_oracle_bert_matches_reference_vectors():
+    fx = gc.load("bert_tiny")
+    m = towers.OBertModel(**gc.TINY_BERT)
+    # the reference wraps the HF model as `.bert`; procedural names carry that prefix
+    holder = torch.nn.Module()
+    holder.bert = m
+    load_procedural(holder, gc.SEED + 70).train()
+    hidden = m(fx["ids"], fx["mask"])
+    _close(hidden, fx["hidden"], "bert hidden")
+    _close(hidden[:, 0], fx["cls"], "bert cls")
+    (hidden * fx["cot"]).sum().backward()
+    grads = {"bert." + k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    for k, g in fx["gw"].items():
+        # key.bias gradients are analytically zero (softmax is shift invariant): both sides hold f32 noise
+        _close(grads[k], g, f"bert grad {k}", rtol=2e-4, atol=2e-5)
+    assert all(k.startswith("bert.pooler") for k in set(grads) ^ set(fx["gw"]))
+
+
+def test_oracle_bert_matches_installed_transformers():
+    tr = pytest.importorskip("transformers")
+    cfg = dict(gc.TINY_BERT)
+    hf = tr.BertModel(tr.BertConfig(**cfg)).eval()
+    m = towers.OBertModel(**cfg).eval()
+    load_procedural(m, 7)
+    missing, unexpected = hf.load_state_dict(m.state_dict(), strict=False)
+    assert not unexpected and all("position_ids" in k or "token_type_ids" in k for k in missing)
+    ids = torch.randint(0, cfg["vocab_size"], (3, 20), generator=torch.Generator().manual_seed(1))
+    mask = torch.ones(3, 20, dtype=torch.long)
+    mask[1, 11:] = 0
+    mask[2, 3:] = 0
+    with torch.no_grad():
+        ref = hf(input_ids=ids, attention_mask=mask).last_hidden_state
+        got = m(ids, mask)
+    _close(got, ref, "oracle vs transformers")
+
+
+@pytest.mark.parametrize("name", sorted(gc.E2E_CASES))
+def test_oracle_e2e_matches_reference_vectors(name):
+    seed, kw = gc.E2E_CASES[name]
+    fx = gc.load(name)
+    images, ids, mask, labels, tab = gc.e2e_inputs()
+    m = om.OMultimodalBaselineModel(bert_cfg=gc.TINY_BERT, **gc.E2E_COMMON, **kw)
+    load_procedural(m, seed).train()
+    logits = gc.e2e_forward(m, name, kw, images, ids, mask, tab)
+    _close(logits, fx["logits"], f"{name}: logits", rtol=1e-4)
+    assert torch.equal(logits.argmax(1), fx["logits"].argmax(1))
+    loss = torch.nn.functional.cross_entropy(logits, labels, label_smoothing=0.02)
+    _close(loss, fx["loss"], f"{name}: loss", rtol=1e-4)
+    loss.backward()
+    params = dict(m.named_parameters())
+    for k, n in fx["gnorm"].items():
+        _close(params[k].grad.norm(), n, f"{name}: |grad {k}|", rtol=5e-3, atol=1e-7)
+    nograd = sorted(k for k, p in params.items() if p.grad is None)
+    assert nograd == sorted(str(s) for s in fx["nograd"])
+    m.eval()
+    with torch.no_grad():
+        ev = m(images, ids, mask, tabular_input=tab if kw.get("tabular_enabled") else None)
+    _close(ev, gc.load(name + "_eval")["logits"], f"{name}: eval logits", rtol=1e-4)
+
+
+@pytest.mark.parametrize("loss_class", ["KL_loss", "text_image_textimage_loss"])
+def test_oracle_mibf_matches_reference_vectors(loss_class):
+    fx = gc.load(f"e2e_mibf_{loss_class}")
+    images, ids, mask, labels = gc.mibf_inputs()
+    m = om.OResnet50WithOurs(6, gc.MIBF_BERT, loss_class)
+    load_procedural(m, gc.SEED + 200).train()
+    out = m({"input_ids": ids, "attention_mask": mask, "transformed_image": images})
+    for k, fk in (("image_text", "logits"), ("text", "text"), ("image", "image")):
+        _close(out[k], fx[fk], f"mibf {k}", rtol=1e-4)
+    loss = m.cal_loss(out, labels)
+    _close(loss, fx["loss"], "mibf loss", rtol=1e-4)
+    loss.backward()
+    params = dict(m.named_parameters())
+    for k, n in fx["gnorm"].items():
+        _close(params[k].grad.norm(), n, f"mibf |grad {k}|", rtol=5e-3, atol=1e-7)
+    # unused parameters keep grad None (DDP find_unused_parameters semantics, train_resnet.py:134)
+    nograd = sorted(k for k, p in params.items() if p.grad is None)
+    assert nograd == sorted(str(s) for s in fx["nograd"])
+    assert any(k.startswith("I2Iattention") for k in nograd) and any("pooler" in k for k in nograd)
+
+
+def test_resnet_known_answers():
+    counts = {"resnet18": 11689512, "resnet34": 21797672, "resnet50": 25557032}
+    for name, n in counts.items():
+        m = towers.oresnet(name)
+        assert sum(p.numel() for p in m.parameters()) == n
+    keys = set(towers.oresnet("resnet50").state_dict())
+    for k in ("conv1.weight", "bn1.running_var", "layer1.0.downsample.0.weight", "layer1.0.downsample.1.num_batches_tracked",
+              "layer4.2.conv3.weight", "layer3.5.bn2.bias", "fc.weight"):
+        assert k in keys
+    r50 = towers.oresnet("resnet50")
+    r50.fc = torch.nn.Linear(2048, 768)
+    assert sum(p.numel() for p in r50.parameters()) == 25081664
+
+
+def test_focal_and_supcon_basics():
+    z = torch.randn(8, 7, generator=torch.Generator().manual_seed(3))
+    y = torch.randint(0, 7, (8,), generator=torch.Generator().manual_seed(4))
+    assert torch.allclose(om.ofocal(z, y, gamma=0.0), torch.nn.functional.cross_entropy(z, y))
+    f = torch.randn(8, 16, generator=torch.Generator().manual_seed(5))
+    assert om.osupcon(f, y).isfinite()
+
+
+# ------------------------------------------------------------------------------ product, host side only
+def test_c_abi_exports_every_declared_symbol():
+    import hamspine._lib as L
+    lib = L.lib()
+    syms = L.exported_symbols()
+    assert len(syms) >= 60
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    assert lib.hs_version() >= 100
+
+
+def test_product_refuses_cpu_tensors():
+    import hamspine
+    from hamspine import functional as F
+    with pytest.raises(hamspine.HamspineError):
+        F.linear(torch.zeros(2, 8), torch.zeros(4, 8), None)
+
+
+def test_product_state_dict_keys_match_oracle(tmp_path):
+    import model as product_model
+    from mibf_net.model_resnet import Resnet50WithOurs
+    d = gc.save_bert_dir(gc.TINY_BERT, str(tmp_path / "bert"))
+    for name, (seed, kw) in gc.E2E_CASES.items():
+        pm = product_model.MultimodalBaselineModel(pretrained_image=False, image_weights_path=None, text_model_name=d,
+                                                   **gc.E2E_COMMON, **kw)
+        o = om.OMultimodalBaselineModel(bert_cfg=gc.TINY_BERT, **gc.E2E_COMMON, **kw)
+        pk = {k: tuple(v.shape) for k, v in pm.state_dict().items()}
+        ok = {k: tuple(v.shape) for k, v in o.state_dict().items()}
+        assert pk == ok, f"{name}: {set(pk) ^ set(ok)}"
+        assert "image_encoder.stem.0.weight" in pk and "image_encoder.model.conv1.weight" in pk
+    d2 = gc.save_bert_dir(gc.MIBF_BERT, str(tmp_path / "bert768"))
+    pm = Resnet50WithOurs(num_labels=6, bert_path=d2)
+    o = om.OResnet50WithOurs(6, gc.MIBF_BERT)
+    assert {k: tuple(v.shape) for k, v in pm.state_dict().items()} == {k: tuple(v.shape) for k, v in o.state_dict().items()}
+    assert sum(p.numel() for p in pm.image_encoder.parameters()) == 25081664
+
+
+def test_product_param_counts_headline():
+    from hamspine.nn import BertConfig, BertModel, resnet18, resnet34, resnet50
+    assert sum(p.numel() for p in resnet18().parameters()) == 11689512
+    assert sum(p.numel() for p in resnet34().parameters()) == 21797672
+    assert sum(p.numel() for p in resnet50().parameters()) == 25557032
+    assert sum(p.numel() for p in BertModel(BertConfig()).parameters()) == 109482240
+    import modules.fusion_blocks as fb
+    assert sum(p.numel() for p in fb.FusionModule(768, 256, 8).parameters()) == 1315584
+    assert sum(p.numel() for p in fb.CrossAttentionBlock(768, 256, 8).parameters()) == 460544
+    assert sum(p.numel() for p in fb.BilinearFusionModule(768, 256).parameters()) == 164864
+    from mibf_net.attention import MultiHeadCrossAttention_v2
+    assert sum(p.numel() for p in MultiHeadCrossAttention_v2(768, 1).parameters()) == 3543552
