@@ -1,0 +1,329 @@
+"""GPU parity tests: the HIP product path against (a) the golden vectors produced by running the reference
+and (b) the CPU oracle on identical seeded weights and inputs.
+
+Tolerances
+  f32 mode : exact-f32 MFMA; only the summation order differs from the CPU -> |err| <= 1e-4 * max|ref| on
+             outputs / logits / losses (the north-star bound), argmax class indices bit-exact,
+             gradients 5e-4 relative to their max (they pass through up to 20 conv+BN layers).
+  bf16 mode: bf16 activations with f32 accumulation -> 3e-2 relative on logits, 8e-2 on gradient norms.
+"""
+import pytest
+import torch
+
+import golden_cases as gc
+
+pytestmark = pytest.mark.gpu
+
+import hamspine  # noqa: E402
+from oracle import models as om  # noqa: E402
+from oracle import towers  # noqa: E402
+from oracle.procedural import load_procedural, procedural_state_dict  # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _f32_mode():
+    hamspine.set_compute_dtype("f32")
+    yield
+    hamspine.set_compute_dtype("bf16")
+
+
+def _close(a, b, what, rtol, atol=2e-6):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    scale = max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item()
+    assert err <= rtol * scale + atol, f"{what}: max err {err:.3e} (scale {scale:.3e}, rtol {rtol})"
+
+
+def _to_dev(v):
+    return v.to(DEV) if torch.is_tensor(v) else v
+
+
+# ------------------------------------------------------------------------------------------------------
+# fusion operators / heads / gate / IBFA vs the reference's vectors
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(gc.MODULE_CASES))
+def test_module_matches_reference_vectors(name):
+    seed, _, pfac, caller = gc.MODULE_CASES[name]
+    fx = gc.load(name)
+    m = load_procedural(pfac(), seed).to(DEV).train()
+    inp = {k: (_to_dev(v).clone().requires_grad_(True) if v.is_floating_point() else _to_dev(v)) for k, v in fx["inp"].items()}
+    out = caller(m, inp)
+    _close(out, fx["out"], f"{name}: out", 1e-4)
+    (out.float() * fx["cot"].to(DEV)).sum().backward()
+    for k, g in fx.get("gin", {}).items():
+        _close(inp[k].grad, g, f"{name}: d/d{k}", 5e-4, 1e-6)
+    params = dict(m.named_parameters())
+    for k, g in fx["gw"].items():
+        assert params[k].grad is not None, f"{name}: no grad for {k}"
+        _close(params[k].grad, g, f"{name}: grad {k}", 5e-4, 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------------
+# towers vs oracle
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("arch,hw", [("resnet18", 64), ("resnet50", 64), ("resnet34", 32)])
+def test_resnet_tower_fwd_bwd_matches_oracle(arch, hw):
+    from hamspine.nn import resnet18, resnet34, resnet50
+    build = {"resnet18": resnet18, "resnet34": resnet34, "resnet50": resnet50}[arch]
+    o = load_procedural(towers.oresnet(arch, num_classes=10), 5).train()
+    p = build(num_classes=10)
+    p.load_state_dict(o.state_dict())
+    p = p.to(DEV).train()
+    x = torch.randn(4, 3, hw, hw, generator=torch.Generator().manual_seed(1))
+    cot = torch.randn(4, 10, generator=torch.Generator().manual_seed(2))
+    yo = o(x)
+    (yo * cot).sum().backward()
+    yp = p(x.to(DEV))
+    (yp * cot.to(DEV)).sum().backward()
+    _close(yp, yo, f"{arch} logits", 1e-4)
+    op, pp = dict(o.named_parameters()), dict(p.named_parameters())
+    for k in op:
+        _close(pp[k].grad, op[k].grad, f"{arch} grad {k}", 1e-3, 1e-6)
+    # running statistics follow torch's momentum update (unbiased variance)
+    ob, pb = dict(o.named_buffers()), dict(p.named_buffers())
+    for k in ("bn1.running_mean", "bn1.running_var", "layer2.0.downsample.1.running_var", "layer4.1.bn2.running_mean"):
+        _close(pb[k], ob[k], f"{arch} buffer {k}", 1e-4)
+    assert p.state_dict()["bn1.num_batches_tracked"].item() == 1
+    # eval mode (running statistics)
+    o.eval()
+    p.eval()
+    with torch.no_grad():
+        _close(p(x.to(DEV)), o(x), f"{arch} eval logits", 1e-4)
+
+
+def test_bert_matches_reference_vectors(tmp_path):
+    from hamspine.nn import BertModel
+    fx = gc.load("bert_tiny")
+    d = gc.save_bert_dir(gc.TINY_BERT, str(tmp_path / "bert"))
+    m = BertModel.from_pretrained(d)
+    holder = torch.nn.Module()
+    holder.bert = m
+    load_procedural(holder, gc.SEED + 70)
+    holder.to(DEV).train()
+    hidden = m(input_ids=fx["ids"].to(DEV), attention_mask=fx["mask"].to(DEV)).last_hidden_state
+    _close(hidden, fx["hidden"], "bert hidden", 1e-4)
+    (hidden * fx["cot"].to(DEV)).sum().backward()
+    grads = {"bert." + k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    for k, g in fx["gw"].items():
+        _close(grads[k], g, f"bert grad {k}", 1e-3, 2e-5)
+    assert m.pooler.dense.weight.grad is None
+
+
+def test_bert_base_shape_bf16_and_dropout_runs():
+    """bert-base dims at the benchmark shape: bf16 vs f32 product agree loosely; train-mode dropout is
+    seeded and changes the output."""
+    from hamspine.nn import BertConfig, BertModel
+    cfg = BertConfig(num_hidden_layers=2)
+    m = BertModel(cfg).to(DEV)
+    ids = torch.randint(1000, 30522, (4, 128), device=DEV)
+    mask = torch.ones(4, 128, dtype=torch.long, device=DEV)
+    mask[1, 77:] = 0
+    m.eval()
+    with torch.no_grad():
+        h32 = m(input_ids=ids, attention_mask=mask).last_hidden_state
+        hamspine.set_compute_dtype("bf16")
+        h16 = m(input_ids=ids, attention_mask=mask).last_hidden_state
+    assert h16.dtype == torch.bfloat16
+    _close(h16, h32, "bert bf16 vs f32", 5e-2, 5e-2)
+    m.train()
+    a = m(input_ids=ids, attention_mask=mask).last_hidden_state
+    b = m(input_ids=ids, attention_mask=mask).last_hidden_state
+    assert not torch.equal(a, b)
+    a.float().sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in m.named_parameters() if "pooler" not in n)
+
+
+# ------------------------------------------------------------------------------------------------------
+# end-to-end models vs the reference's vectors
+# ------------------------------------------------------------------------------------------------------
+def _build_product_e2e(kw, tmp_path, seed):
+    import model as product_model
+    d = gc.save_bert_dir(gc.TINY_BERT, str(tmp_path / "bert"))
+    m = product_model.MultimodalBaselineModel(pretrained_image=False, image_weights_path=None, text_model_name=d,
+                                              **gc.E2E_COMMON, **kw)
+    load_procedural(m, seed)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("name", sorted(gc.E2E_CASES))
+def test_e2e_baseline_matches_reference_vectors(name, tmp_path):
+    from hamspine import functional as F
+    seed, kw = gc.E2E_CASES[name]
+    fx = gc.load(name)
+    images, ids, mask, labels, tab = [t.to(DEV) for t in gc.e2e_inputs()]
+    m = _build_product_e2e(kw, tmp_path, seed).train()
+    logits = gc.e2e_forward(m, name, kw, images, ids, mask, tab)
+    assert logits.dtype == torch.float32
+    _close(logits, fx["logits"], f"{name}: logits", 1e-4)
+    assert torch.equal(logits.argmax(1).cpu(), fx["logits"].argmax(1)), "argmax class indices must be bit-exact"
+    loss = F.cross_entropy(logits, labels, label_smoothing=0.02)
+    _close(loss, fx["loss"], f"{name}: loss", 1e-4)
+    loss.backward()
+    params = dict(m.named_parameters())
+    for k, n in fx["gnorm"].items():
+        assert params[k].grad is not None, f"{name}: no grad for {k}"
+        _close(params[k].grad.norm(), n, f"{name}: |grad {k}|", 5e-3, 1e-7)
+    for k, g in fx["gw"].items():
+        _close(params[k].grad, g, f"{name}: grad {k}", 2e-3, 1e-6)
+    nograd = sorted(k for k, p in params.items() if p.grad is None)
+    assert nograd == sorted(str(s) for s in fx["nograd"])
+    m.eval()
+    with torch.no_grad():
+        ev = m(images, ids, mask, tabular_input=tab if kw.get("tabular_enabled") else None)
+    _close(ev, gc.load(name + "_eval")["logits"], f"{name}: eval logits", 1e-4)
+
+
+@pytest.mark.parametrize("loss_class", ["KL_loss", "text_image_textimage_loss"])
+def test_e2e_mibf_matches_reference_vectors(loss_class, tmp_path):
+    from mibf_net.model_resnet import Resnet50WithOurs
+    fx = gc.load(f"e2e_mibf_{loss_class}")
+    images, ids, mask, labels = [t.to(DEV) for t in gc.mibf_inputs()]
+    d = gc.save_bert_dir(gc.MIBF_BERT, str(tmp_path / "bert768"))
+    m = Resnet50WithOurs(num_labels=6, loss_class=loss_class, bert_path=d)
+    load_procedural(m, gc.SEED + 200)
+    m = m.to(DEV).train()
+    out = m({"input_ids": ids, "attention_mask": mask, "transformed_image": images})
+    for k, fk in (("image_text", "logits"), ("text", "text"), ("image", "image")):
+        _close(out[k], fx[fk], f"mibf {k}", 1e-4)
+        assert torch.equal(out[k].argmax(1).cpu(), fx[fk].argmax(1))
+    loss = m.cal_loss(out, labels)
+    _close(loss, fx["loss"], "mibf loss", 1e-4)
+    loss.backward()
+    params = dict(m.named_parameters())
+    for k, n in fx["gnorm"].items():
+        _close(params[k].grad.norm(), n, f"mibf |grad {k}|", 5e-3, 1e-7)
+    nograd = sorted(k for k, p in params.items() if p.grad is None)
+    assert nograd == sorted(str(s) for s in fx["nograd"])
+
+
+def test_e2e_bf16_mode_close_to_reference(tmp_path):
+    from hamspine import functional as F
+    name = "e2e_basic_mlp"
+    seed, kw = gc.E2E_CASES[name]
+    fx = gc.load(name)
+    images, ids, mask, labels, tab = [t.to(DEV) for t in gc.e2e_inputs()]
+    hamspine.set_compute_dtype("bf16")
+    m = _build_product_e2e(kw, tmp_path, seed).train()
+    logits = gc.e2e_forward(m, name, kw, images, ids, mask, tab)
+    _close(logits, fx["logits"], "bf16 logits", 3e-2, 3e-2)
+    loss = F.cross_entropy(logits, labels, label_smoothing=0.02)
+    _close(loss, fx["loss"], "bf16 loss", 3e-2)
+    loss.backward()
+    params = dict(m.named_parameters())
+    bad = []
+    for k, n in fx["gnorm"].items():
+        g = params[k].grad.norm().item()
+        if abs(g - n.item()) > 8e-2 * n.item() + 1e-6:
+            bad.append((k, g, n.item()))
+    assert len(bad) <= len(fx["gnorm"]) // 20, bad[:10]
+
+
+def test_state_dict_roundtrip_and_hooks(tmp_path):
+    """checkpoint fidelity (strict load, alias keys) and hookable stage boundaries (reference
+    scripts/evaluate.py:111, scripts/run_analysis.py:126-133, analysis_tools.py:154)."""
+    seed, kw = gc.E2E_CASES["e2e_basic_mlp"]
+    m = _build_product_e2e(kw, tmp_path, seed)
+    o = om.OMultimodalBaselineModel(bert_cfg=gc.TINY_BERT, **gc.E2E_COMMON, **kw)
+    o.load_state_dict(m.state_dict(), strict=True)          # product checkpoint loads into the reference layout
+    m.load_state_dict(o.state_dict(), strict=True)
+    seen = {}
+    hs = [m.image_encoder.stem.register_forward_hook(lambda mod, i, out: seen.__setitem__("stem", out)),
+          m.image_encoder.layer4[-1].register_forward_hook(lambda mod, i, out: seen.__setitem__("l4", out)),
+          m.fusion.register_forward_hook(lambda mod, i, out: seen.__setitem__("fusion", out)),
+          m.image_encoder.layer4[-1].register_full_backward_hook(lambda mod, gi, go: seen.__setitem__("g4", go[0]))]
+    images, ids, mask, labels, tab = [t.to(DEV) for t in gc.e2e_inputs()]
+    m.eval()
+    logits = m(images, ids, mask)
+    logits[:, 0].sum().backward()
+    assert seen["stem"].shape == (4, 64, 16, 16) and seen["l4"].shape == (4, 512, 2, 2)
+    assert seen["fusion"].shape == (4, 64) and seen["g4"].shape == (4, 512, 2, 2)
+    for h in hs:
+        h.remove()
+    # frozen encoders: no parameter gradients there, heads still train (scripts/train.py:214-219)
+    m.zero_grad(set_to_none=True)
+    m.freeze_encoders()
+    m.train()
+    m(images, ids, mask).sum().backward()
+    assert all(p.grad is None for p in m.image_encoder.parameters())
+    assert all(p.grad is None for p in m.text_encoder.parameters())
+    assert m.classifier[0].weight.grad is not None
+
+
+# ------------------------------------------------------------------------------------------------------
+# op-level checks that the module tests do not isolate
+# ------------------------------------------------------------------------------------------------------
+def test_cross_entropy_weights_and_smoothing():
+    from hamspine import functional as F
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(32, 7, generator=g)
+    y = torch.randint(0, 7, (32,), generator=g)
+    w = torch.rand(7, generator=g) + 0.5
+    for weight, sm in ((None, 0.0), (None, 0.02), (w, 0.0), (w, 0.1)):
+        zc = z.clone().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(zc, y, weight=weight, label_smoothing=sm)
+        ref.backward()
+        zg = z.to(DEV).requires_grad_(True)
+        got = F.cross_entropy(zg, y.to(DEV), None if weight is None else weight.to(DEV), sm)
+        (got * 2.0).backward()
+        _close(got, ref, f"ce w={weight is not None} sm={sm}", 1e-5)
+        _close(zg.grad, 2.0 * zc.grad, "ce grad", 1e-4, 1e-7)
+
+
+def test_focal_loss_and_entropy():
+    from hamspine import small as S
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(16, 7, generator=g)
+    y = torch.randint(0, 7, (16,), generator=g)
+    zc = z.clone().requires_grad_(True)
+    ref = om.ofocal(zc, y)
+    ref.backward()
+    zg = z.to(DEV).requires_grad_(True)
+    got = S.focal_loss(zg, y.to(DEV))
+    got.backward()
+    _close(got, ref, "focal", 1e-5)
+    _close(zg.grad, zc.grad, "focal grad", 1e-4, 1e-7)
+
+
+def test_maxpool_ties_follow_torch_scan_order():
+    """post-ReLU maps are full of exact ties (zeros): the arg-max must be torch's first-in-scan-order."""
+    import ctypes as C
+    from hamspine import _lib as L
+    from hamspine import rt
+    x = torch.zeros(1, 8, 6, 6)
+    x[0, :, 2, 3] = 1.0
+    xc = x.clone().requires_grad_(True)
+    y = torch.nn.functional.max_pool2d(xc, 3, 2, 1)
+    cot = torch.arange(y.numel(), dtype=torch.float32).view_as(y)
+    (y * cot).sum().backward()
+    xg = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    yg = torch.empty((1, 8, 3, 3), device=DEV).contiguous(memory_format=torch.channels_last)
+    idx = torch.empty(yg.numel(), dtype=torch.uint8, device=DEV)
+    lib = L.lib()
+    L.check(lib.hs_maxpool_fwd(L.HS_F32, rt.p(xg), rt.p(yg), rt.p(idx), 1, 6, 6, 8, 3, 2, 1, rt.stream()), "maxpool")
+    assert torch.equal(yg.cpu(), y.detach())
+    dyg = cot.to(DEV).contiguous(memory_format=torch.channels_last)
+    dxg = torch.empty_like(xg)
+    L.check(lib.hs_maxpool_bwd(L.HS_F32, rt.p(dyg), rt.p(idx), rt.p(dxg), 1, 6, 6, 8, 3, 2, 1, rt.stream()), "maxpool_bwd")
+    assert torch.equal(dxg.cpu(), xc.grad)
+
+
+def test_fused_adamw_matches_torch():
+    from hamspine.optim import FusedAdamW
+    g = torch.Generator().manual_seed(2)
+    ps = [torch.randn(s, generator=g) for s in ((300, 7), (5,), (64, 3, 3, 3))]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    got = [p.clone().to(DEV).requires_grad_(True) for p in ps]
+    o_ref = torch.optim.AdamW(ref, lr=1e-2, weight_decay=0.05)
+    o_got = FusedAdamW(got, lr=1e-2, weight_decay=0.05)
+    for step in range(3):
+        for r, q in zip(ref, got):
+            gr = torch.randn(r.shape, generator=g)
+            r.grad = gr.clone()
+            q.grad = gr.to(DEV)
+        o_ref.step()
+        o_got.step()
+    for r, q in zip(ref, got):
+        _close(q, r, "adamw param", 1e-5, 1e-6)
