@@ -109,6 +109,11 @@ hs_status hs_gemm(const hs_gemm_params* p, void* stream);
 int64_t hs_gemm_splitk_ws_bytes(const hs_gemm_params* p);
 /* heuristic split-K factor for a (M,N,K) problem so that the grid fills 256 CUs. */
 int32_t hs_gemm_suggest_split(int32_t M, int32_t N, int32_t K, int32_t dtype);
+/* Optional timing of every GEMM-core launch with HIP events on its stream (measurement only).
+   Classes: 0 bf16 GEMM, 1 bf16 implicit-GEMM conv, 2 f32 GEMM, 3 f32 conv.  hs_prof_collect synchronises the
+   device, fills 4 entries of algorithmic flops / elapsed ms / launch counts and clears the records. */
+void hs_prof_enable(int32_t on);
+hs_status hs_prof_collect(double* flops, double* ms, int64_t* launches);
 
 /* ------------------------------------------------------------------------------------------- */
 /* BatchNorm2d over NHWC activations viewed as [M = N*H*W][C]                                    */

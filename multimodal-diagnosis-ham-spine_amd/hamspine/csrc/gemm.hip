@@ -1,6 +1,7 @@
 // host side of the GEMM / implicit-GEMM core: argument checking, tile selection, split-K.
 #include <mutex>
 #include <unordered_set>
+#include <vector>
 #include <stdarg.h>
 #include "gemm_launch.h"
 
@@ -20,6 +21,41 @@ bool lds_attr_needed(const void* fn) {
     static std::unordered_set<const void*> seen;
     std::lock_guard<std::mutex> lk(mu);
     return seen.insert(fn).second;
+}
+
+// ------------------------------------------------------------------------------------------------
+// optional per-launch timing of the GEMM kernels (bench.py's roofline leg): HIP events are recorded on
+// the launch stream around every main kernel; classes: 0 bf16 GEMM, 1 bf16 conv, 2 f32 GEMM, 3 f32 conv
+// ------------------------------------------------------------------------------------------------
+struct ProfRec {
+    hipEvent_t a, b;
+    double flops;
+    int cls;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+
+static bool prof_begin(hipStream_t s, double flops, int cls, ProfRec& r) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_on) return false;
+    if (!g_prof_pool.empty()) {
+        r.a = g_prof_pool.back().first;
+        r.b = g_prof_pool.back().second;
+        g_prof_pool.pop_back();
+    } else if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+        return false;
+    }
+    r.flops = flops;
+    r.cls = cls;
+    hipEventRecord(r.a, s);
+    return true;
+}
+static void prof_end(hipStream_t s, ProfRec& r) {
+    hipEventRecord(r.b, s);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(r);
 }
 
 static int combo_of(int ak, int bk) {
@@ -172,8 +208,11 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     }
     dim3 grid(a.tiles_m * a.tiles_n, 1, split > 1 ? split : batch);
     int st;
+    ProfRec rec;
+    const bool timed = prof_begin(stream, 2.0 * p->M * p->N * (double)p->K * batch, (bf16 ? 0 : 2) + (conv ? 1 : 0), rec);
     if (bf16) st = conv ? launch_bf16_conv(cfg, combo, a, grid, stream) : launch_bf16_plain(cfg, combo, a, grid, stream);
     else st = conv ? launch_f32_conv(cfg, combo, a, grid, stream) : launch_f32_plain(cfg, combo, vec, a, grid, stream);
+    if (timed) prof_end(stream, rec);
     HS_PROPAGATE(st);
     if (split > 1) {
         const long long work = (long long)p->M * ((p->N + 3) / 4);
@@ -188,6 +227,31 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
 }  // namespace hs
 
 extern "C" {
+void hs_prof_enable(int32_t on) {
+    std::lock_guard<std::mutex> lk(hs::g_prof_mu);
+    hs::g_prof_on = on != 0;
+}
+/* Synchronises the device, then sums flops / milliseconds / launches per class (4 entries each) and clears. */
+hs_status hs_prof_collect(double* flops, double* ms, int64_t* launches) {
+    HS_CHECK_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(hs::g_prof_mu);
+    for (int i = 0; i < 4; ++i) {
+        flops[i] = 0;
+        ms[i] = 0;
+        launches[i] = 0;
+    }
+    for (auto& r : hs::g_prof) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            flops[r.cls] += r.flops;
+            ms[r.cls] += t;
+            launches[r.cls] += 1;
+        }
+        hs::g_prof_pool.emplace_back(r.a, r.b);
+    }
+    hs::g_prof.clear();
+    return HS_OK;
+}
 const char* hs_last_error(void) { return hs::last_error(); }
 int hs_version(void) { return 100; }
 int hs_device_ok(void) {

@@ -1,0 +1,164 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, RCCL over xGMI through
+torch.distributed (backend "nccl" is RCCL on ROCm; "gloo" on CPU for the tests).
+
+Replaces torch.nn.parallel.DistributedDataParallel(find_unused_parameters=True) as used by reference
+mibf_net/train_resnet.py:84-90,133-134 for the synchronous-SGD semantics that matter to the step:
+  * constructor: parameters and buffers follow rank 0 (broadcast),
+  * backward: gradients are averaged over ranks before optimizer.step(); parameters that took no part in
+    the forward keep grad None,
+  * per-rank BatchNorm statistics (no SyncBN), per-rank batch of 32 (weak scaling).
+
+MI355X-first design
+  * gradients live in a few large flat buckets (default 128 MiB, sized for 288 GB HBM and for xGMI's
+    per-link bandwidth: few, large collectives).  The HIP backward nodes write parameter gradients
+    straight into the bucket (hamspine.rt.grad_arena: zero-copy, no flatten pass),
+  * buckets are laid out in reverse parameter order (~ the order backward produces them); when the last
+    gradient of a bucket lands, its all-reduce is enqueued on a side HIP stream behind an event, so the
+    collective overlaps the rest of backward,
+  * one wait on the side stream before optimizer.step() (`finish()`, also run automatically at the end of
+    each backward through an autograd-engine callback).
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import rt
+
+
+class _Bucket:
+    def __init__(self, params, device):
+        self.params = params
+        self.offsets = []
+        n = 0
+        for p in params:
+            self.offsets.append(n)
+            n += (p.numel() + 63) // 64 * 64          # 256-byte aligned slots
+        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self.views = [self.flat[o:o + p.numel()].as_strided(p.shape, p.stride()) for p, o in zip(params, self.offsets)]
+        self.ready = 0
+        self.have = [False] * len(params)
+        self.launched = False
+        self.work = None
+
+
+class DataParallel(nn.Module):
+    def __init__(self, module, process_group=None, bucket_mb=128, broadcast_buffers=True):
+        super().__init__()
+        self.module = module
+        self.pg = process_group
+        self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
+        self.broadcast_buffers = broadcast_buffers
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.device = params[0].device
+        self.on_gpu = self.device.type == "cuda"
+        # rank 0's parameters / buffers win (DDP constructor semantics)
+        if self.world > 1:
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, src=0, group=self.pg)
+        # buckets in reverse parameter order
+        cap = int(bucket_mb * (1 << 20) // 4)
+        self.buckets, cur, cur_n = [], [], 0
+        for p in reversed(params):
+            if cur and cur_n + p.numel() > cap:
+                self.buckets.append(_Bucket(cur, self.device))
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            self.buckets.append(_Bucket(cur, self.device))
+        self._where = {}
+        for b in self.buckets:
+            for i, p in enumerate(b.params):
+                self._where[p] = (b, i)
+                rt.grad_arena_register(p, b.views[i])
+                p.register_post_accumulate_grad_hook(self._on_grad)
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        self._callback_queued = False
+        self._dirty = False
+        self._avg_op = dist.ReduceOp.AVG if (self.on_gpu and self.world > 1) else dist.ReduceOp.SUM
+
+    # ------------------------------------------------------------------------------------------
+    def sync_buffers(self):
+        """Buffers (BatchNorm running statistics) follow rank 0, as with DDP's broadcast_buffers=True.
+        Train-mode BatchNorm never reads them, so instead of ~100 tiny broadcasts per forward the sync is
+        one coalesced broadcast whenever they become observable: state_dict(), eval(), or on request."""
+        if self.world > 1 and self.broadcast_buffers:
+            bufs = [b.data for b in self.module.buffers() if b.is_floating_point()]
+            if bufs:
+                dist._broadcast_coalesced(self.pg or dist.group.WORLD, bufs, 256 << 20, 0)
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+    def train(self, mode=True):
+        if not mode and self.training:
+            self.sync_buffers()
+        return super().train(mode)
+
+    def _on_grad(self, p):
+        b, i = self._where[p]
+        view = b.views[i]
+        if p.grad.data_ptr() != view.data_ptr():             # gradient produced outside the arena: copy once
+            view.copy_(p.grad)
+            p.grad = view
+        self._dirty = True
+        if not b.have[i]:
+            b.have[i] = True
+            b.ready += 1
+        if not self._callback_queued:
+            torch.autograd.Variable._execution_engine.queue_callback(self.finish)
+            self._callback_queued = True
+        if b.ready == len(b.params) and not b.launched:
+            self._launch(b)
+
+    def _launch(self, b):
+        b.launched = True
+        if self.world == 1:
+            return
+        if self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                b.work = dist.all_reduce(b.flat, op=self._avg_op, group=self.pg, async_op=True)
+        else:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def finish(self):
+        """Reduce the buckets that never filled (unused parameters) and wait for all collectives.  Called by
+        the autograd engine at the end of backward; safe to call again before optimizer.step()."""
+        self._callback_queued = False
+        if not self._dirty:
+            return
+        self._dirty = False
+        for b in self.buckets:
+            if not b.launched and b.ready > 0:
+                for i, got in enumerate(b.have):
+                    if not got:
+                        b.views[i].zero_()                   # absent on every rank alike: contributes zeros
+                self._launch(b)
+        for b in self.buckets:
+            if b.work is not None:
+                b.work.wait()
+                b.work = None
+                if self._avg_op == dist.ReduceOp.SUM and self.world > 1:
+                    b.flat.div_(self.world)
+        if self.on_gpu and self.world > 1:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        for b in self.buckets:
+            for i, p in enumerate(b.params):
+                if not b.have[i] and p.grad is not None and p.grad.data_ptr() == b.views[i].data_ptr():
+                    p.grad = None                            # unused this step: keep DDP's grad=None contract
+            b.ready = 0
+            b.have = [False] * len(b.params)
+            b.launched = False
+
+    def zero_grad(self, set_to_none=True):
+        self.module.zero_grad(set_to_none=set_to_none)
+
+    def state_dict(self, *a, **k):
+        self.sync_buffers()
+        return self.module.state_dict(*a, **k)
+
+    def load_state_dict(self, *a, **k):
+        return self.module.load_state_dict(*a, **k)

@@ -43,7 +43,7 @@ def _lin(in_f, out_f, w, b, dw=None, db=None, w_off=0, b_off=0):
 
 
 def _grad_like(t, needed):
-    return torch.empty_like(t) if needed else None
+    return rt.grad_buffer_like(t) if needed else None
 
 
 # =================================================================================================
@@ -220,9 +220,9 @@ class BertEmbedFn(Function):
         L.check(_lib().hs_layernorm_bwd(hdt, rt.p(g), rt.p(ssum), rt.p(gamma), rt.p(stats), rt.p(stats, M * 4), rt.p(dsum),
                                         rt.p(dgamma), rt.p(dbeta), rt.p(ws), wsb, M, H, rt.stream()), "hs_layernorm_bwd")
         need_w, need_p, need_t = ctx.needs_input_grad[2], ctx.needs_input_grad[3], ctx.needs_input_grad[4]
-        dword = torch.zeros_like(word) if need_w else None
-        dpos = torch.zeros_like(pos) if need_p else None
-        dtyp = torch.zeros_like(typ) if need_t else None
+        dword = rt.grad_buffer_like(word).zero_() if need_w else None
+        dpos = rt.grad_buffer_like(pos).zero_() if need_p else None
+        dtyp = rt.grad_buffer_like(typ).zero_() if need_t else None
         if need_w or need_p:
             L.check(_lib().hs_bert_embed_bwd(hdt, rt.p(ids), rt.p(dsum), rt.p(dword), rt.p(dpos), B, Lq, H, word.shape[0],
                                              ctx.pad_id, rt.stream()), "hs_bert_embed_bwd")

@@ -179,11 +179,16 @@ class BertModel(nn.Module):
         config = BertConfig.from_json_file(os.path.join(path, "config.json"))
         model = cls(config)
         st_path = os.path.join(path, "model.safetensors")
+        bin_path = os.path.join(path, "pytorch_model.bin")
         if os.path.exists(st_path):
             from safetensors.torch import load_file
             sd = load_file(st_path)
+        elif os.path.exists(bin_path):
+            sd = torch.load(bin_path, map_location="cpu")
+        elif os.environ.get("HAMSPINE_BERT_RANDOM_INIT") == "1":
+            return model     # synthetic benchmarks: architecture from config.json, random weights (stated in `data`)
         else:
-            sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu")
+            raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {path}")
         model.load_hf_state_dict(sd)
         return model
 

@@ -43,6 +43,27 @@ def reset_seed(base=None):
         _seed_state["ctr"] = 0
 
 
+_grad_arena = {}
+
+
+def grad_arena_register(param, view):
+    """hamspine.ddp: parameter -> preallocated slot of a flat gradient bucket (same shape / strides)."""
+    _grad_arena[param.data_ptr()] = view
+
+
+def grad_arena_clear():
+    _grad_arena.clear()
+
+
+def grad_buffer_like(param):
+    """Where a backward node writes d(param): the bucket slot when data-parallel training registered one
+    (zero-copy bucketing), else a fresh tensor laid out like the parameter."""
+    v = _grad_arena.get(param.data_ptr())
+    if v is not None and v.shape == param.shape:
+        return v.detach()      # fresh alias: autograd may adopt it as .grad without cloning
+    return torch.empty_like(param)
+
+
 def hs_dtype(t_or_dtype):
     dt = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
     if dt == torch.bfloat16:
