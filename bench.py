@@ -118,6 +118,7 @@ def gpu_leg(args, rank, world, local_rank):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
     final_loss = loss.item()
+    log(f"rank {rank}: {args.steps} steps in {dt:.3f} s -> {dt / args.steps * 1e3:.2f} ms/step, loss {final_loss:.4f}")
 
     # ---- roofline leg: per-launch HIP events around the dominant kernel family, two extra steps ----------
     lib = L.lib()
@@ -149,11 +150,15 @@ def gpu_leg(args, rank, world, local_rank):
     return dt, final_loss, roofline, nparams
 
 
-def cpu_leg(sample_batch=8, steps=2):
+def cpu_leg(sample_batch=4, steps=2):
     """The oracle's restatement of the same step on the host cores (kind = "port"), bounded sample."""
     from oracle import models as om
     from oracle.procedural import synthetic_batch
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))      # the GPU box grants 16 host cores per GPU
     torch.set_num_threads(cores)
     bert_cfg = dict(vocab_size=VOCAB, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
                     intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2,
@@ -170,11 +175,14 @@ def cpu_leg(sample_batch=8, steps=2):
         loss = torch.nn.functional.cross_entropy(logits, labels, label_smoothing=0.02)
         loss.backward()
         opt.step()
+    t0 = time.perf_counter()
     step()   # warm-up
+    log(f"cpu oracle warm-up step: {time.perf_counter() - t0:.1f} s on {cores} threads")
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     dt = time.perf_counter() - t0
+    log(f"cpu oracle: {steps} steps of batch {sample_batch} in {dt:.1f} s")
     return {"value": round(sample_batch * steps / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{steps} timed steps (+1 warm-up) of the same C2 train step at batch {sample_batch}, fp32, "
                       f"torch {torch.__version__} CPU, {cores} threads"}
