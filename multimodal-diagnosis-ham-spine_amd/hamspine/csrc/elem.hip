@@ -278,12 +278,27 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     for (long long r = blockIdx.y; r < M; r += gridDim.y) acc += to_f32(x[r * ld + c]);
     ws[(long long)blockIdx.y * N + c] = acc;
 }
-__global__ void colsum_final_kernel(const float* __restrict__ ws, int gy, int N, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ ws, int gy, int N,
+                                                           float* __restrict__ out, int accumulate) {
+    __shared__ float sh[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float acc = 0.f;
-    for (int i = 0; i < gy; ++i) acc += ws[(long long)i * N + c];
-    out[c] = accumulate ? out[c] + acc : acc;
+    if (c < N) {
+        int i = rg;
+        for (; i + 12 < gy; i += 16) {
+            const float v0 = ws[(long long)i * N + c], v1 = ws[(long long)(i + 4) * N + c];
+            const float v2 = ws[(long long)(i + 8) * N + c], v3 = ws[(long long)(i + 12) * N + c];
+            acc += (v0 + v1) + (v2 + v3);
+        }
+        for (; i < gy; i += 4) acc += ws[(long long)i * N + c];
+    }
+    sh[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && c < N) {
+        const float t = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 // ============================================================================================
@@ -628,7 +643,7 @@ static int colsum_t(const void* x, long long M, int N, int ld, float* out, float
     HS_REQUIRE(ws && ws_bytes >= (long long)gy * N * 4, "colsum: workspace too small");
     hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3(ceil_div(N, 256), gy), dim3(256), 0, s, (const T*)x, M, N, ld, ws);
     HS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, ws, gy, N, out, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, s, ws, gy, N, out, accumulate);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }

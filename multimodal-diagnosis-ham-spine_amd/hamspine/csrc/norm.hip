@@ -101,28 +101,46 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const T* __restri
     }
 }
 
-// stage 2: merge row blocks; produce mean / invstd / (scale, shift); update running statistics
-__global__ void bn_stats_final_kernel(const float* __restrict__ ws, int gy, int C, long long M, float eps,
-                                      float momentum, const float* __restrict__ gamma,
-                                      const float* __restrict__ beta, float* __restrict__ running_mean,
-                                      float* __restrict__ running_var, float* __restrict__ mean_out,
-                                      float* __restrict__ invstd_out, float* __restrict__ scale_out,
-                                      float* __restrict__ shift_out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// stage 2: merge row blocks; produce mean / invstd / (scale, shift); update running statistics.
+// One wave per channel: lanes merge a strided subset of the partials (Chan's formula), then a butterfly of
+// pairwise merges -- the order is fixed, so the result is deterministic.
+__device__ __forceinline__ void chan_merge(float& cnt, float& mean, float& m2, float nb, float mb, float m2b) {
+    if (nb > 0.f) {
+        const float n = cnt + nb;
+        const float d = mb - mean;
+        const float w = nb / n;
+        mean += d * w;
+        m2 += m2b + d * d * cnt * w;
+        cnt = n;
+    }
+}
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ ws, int gy, int C, long long M,
+                                                             float eps, float momentum, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var, float* __restrict__ mean_out,
+                                                             float* __restrict__ invstd_out, float* __restrict__ scale_out,
+                                                             float* __restrict__ shift_out) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     float cnt = 0.f, mean = 0.f, m2 = 0.f;
-    for (int b = 0; b < gy; ++b) {
+    for (int b = lane; b < gy; b += 64) {
         const float* p = ws + ((long long)b * C + c) * 3;
-        const float nb = p[0];
-        if (nb > 0.f) {
-            const float n = cnt + nb;
-            const float d = p[1] - mean;
-            const float w = nb / n;
-            mean += d * w;
-            m2 += p[2] + d * d * cnt * w;
-            cnt = n;
-        }
+        chan_merge(cnt, mean, m2, p[0], p[1], p[2]);
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float nb = __shfl_xor(cnt, o, 64), mb = __shfl_xor(mean, o, 64), qb = __shfl_xor(m2, o, 64);
+        // both partners must compute the same merged value: merge (lower lane) + (upper lane) in that order
+        float c0 = cnt, m0 = mean, q0 = m2, c1 = nb, m1 = mb, q1 = qb;
+        if (lane & o) {
+            c0 = nb; m0 = mb; q0 = qb; c1 = cnt; m1 = mean; q1 = m2;
+        }
+        chan_merge(c0, m0, q0, c1, m1, q1);
+        cnt = c0; mean = m0; m2 = q0;
+    }
+    if (lane != 0) return;
     const float var = m2 / (float)M;                   // biased, used for normalisation
     const float invstd = rsqrtf(var + eps);
     mean_out[c] = mean;
@@ -159,12 +177,18 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     constexpr int E = Chunk<T>::N;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long long)gridDim.x * 256) {
         const int c0 = (int)(i % cg) * E;
-        float f[E], r[E];
+        float f[E], r[E], sc[E], sh[E];
         Chunk<T>::unpack(*(const u32x4*)(x + i * E), f);
         if (res) Chunk<T>::unpack(*(const u32x4*)(res + i * E), r);
 #pragma unroll
+        for (int e = 0; e < E; e += 4) {
+            const f32x4 a = *(const f32x4*)(scale + c0 + e), b = *(const f32x4*)(shift + c0 + e);
+            sc[e] = a[0]; sc[e + 1] = a[1]; sc[e + 2] = a[2]; sc[e + 3] = a[3];
+            sh[e] = b[0]; sh[e + 1] = b[1]; sh[e + 2] = b[2]; sh[e + 3] = b[3];
+        }
+#pragma unroll
         for (int e = 0; e < E; ++e) {
-            float v = f[e] * scale[c0 + e] + shift[c0 + e];
+            float v = f[e] * sc[e] + sh[e];
             if (res) v += r[e];
             if (relu) v = fmaxf(v, 0.f);
             f[e] = v;
@@ -231,48 +255,63 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
         }
     }
 }
-__global__ void bn_bwd_final_kernel(const float* __restrict__ ws, int gy, int C, float* __restrict__ dbeta,
-                                    float* __restrict__ dgamma) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// dx = ca*dz + cb*x + cc per channel:  train  ca = g*is, cb = -g*is*is*dgamma/M, cc = -ca*dbeta/M - cb*mean
+//                                      eval   ca = g*is, cb = 0, cc = 0
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ ws, int gy, int C,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, float invM, int train,
+                                                           float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                           float* __restrict__ coef) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     float a = 0.f, b = 0.f;
-    for (int i = 0; i < gy; ++i) {
+    for (int i = lane; i < gy; i += 64) {
         a += ws[((long long)i * C + c) * 2 + 0];
         b += ws[((long long)i * C + c) * 2 + 1];
     }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane != 0) return;
     dbeta[c] = a;
     dgamma[c] = b;
+    const float g = gamma ? gamma[c] : 1.f, is = invstd[c];
+    const float ca = g * is;
+    const float cb = train ? -ca * is * b * invM : 0.f;
+    const float cc = train ? -ca * a * invM - cb * mean[c] : 0.f;
+    coef[c] = ca;
+    coef[C + c] = cb;
+    coef[2 * C + c] = cc;
 }
-// backward stage 2: dx = gamma*invstd*(dz - dbeta/M - xhat*dgamma/M)  [train]   |  gamma*invstd*dz  [eval]
-// optional dres = dz (gradient of the residual branch)
+// backward stage 2: dx = ca*dz + cb*x + cc (coefficients from bn_bwd_final_kernel); optional dres = dz
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y,
-                                                           const T* __restrict__ x, const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd,
-                                                           const float* __restrict__ gamma,
-                                                           const float* __restrict__ dbeta,
-                                                           const float* __restrict__ dgamma, T* __restrict__ dx,
-                                                           T* __restrict__ dres, long long nchunks, int cg, float invM,
-                                                           int relu, int train) {
+                                                           const T* __restrict__ x, const float* __restrict__ coef,
+                                                           T* __restrict__ dx, T* __restrict__ dres, long long nchunks,
+                                                           int cg, int C, int relu) {
     constexpr int E = Chunk<T>::N;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long long)gridDim.x * 256) {
         const int c0 = (int)(i % cg) * E;
-        float g[E], xv[E], yv[E], o[E];
+        float g[E], xv[E], yv[E], o[E], ca[E], cb[E], cc[E];
         Chunk<T>::unpack(*(const u32x4*)(dy + i * E), g);
-        if (train) Chunk<T>::unpack(*(const u32x4*)(x + i * E), xv);
+        Chunk<T>::unpack(*(const u32x4*)(x + i * E), xv);
         if (relu) Chunk<T>::unpack(*(const u32x4*)(y + i * E), yv);
 #pragma unroll
+        for (int e = 0; e < E; e += 4) {
+            const f32x4 a = *(const f32x4*)(coef + c0 + e), b = *(const f32x4*)(coef + C + c0 + e),
+                        c = *(const f32x4*)(coef + 2 * C + c0 + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ca[e + j] = a[j];
+                cb[e + j] = b[j];
+                cc[e + j] = c[j];
+            }
+        }
+#pragma unroll
         for (int e = 0; e < E; ++e) {
-            const int c = c0 + e;
             const float dz = (relu && !(yv[e] > 0.f)) ? 0.f : g[e];
             g[e] = dz;
-            const float sc = (gamma ? gamma[c] : 1.f) * invstd[c];
-            if (train) {
-                const float xh = (xv[e] - mean[c]) * invstd[c];
-                o[e] = sc * (dz - dbeta[c] * invM - xh * dgamma[c] * invM);
-            } else {
-                o[e] = sc * dz;
-            }
+            o[e] = ca[e] * dz + cb[e] * xv[e] + cc[e];
         }
         *(u32x4*)(dx + i * E) = Chunk<T>::pack(o);
         if (dres) *(u32x4*)(dres + i * E) = Chunk<T>::pack(g);
@@ -291,7 +330,7 @@ static int bn_fwd_t(const hs_bn_params* p, hipStream_t s) {
         hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(g.gx, g.gy), dim3(256), 0, s, (const T*)p->x, M, C, g.tpc,
                            (float*)p->ws);
         HS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, (const float*)p->ws, g.gy, C, M,
+        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, (const float*)p->ws, g.gy, C, M,
                            p->eps, p->momentum, p->gamma, p->beta, p->running_mean, p->running_var, p->save_mean,
                            p->save_invstd, p->scale, p->shift);
         HS_LAUNCH_CHECK();
@@ -317,19 +356,19 @@ static int bn_bwd_t(const hs_bn_bwd_params* p, hipStream_t s) {
     const long long M = p->M;
     const int C = p->C;
     ColGeom g = col_geom(M, C, E);
-    HS_REQUIRE(p->ws && p->ws_bytes >= (long long)g.gy * C * 2 * 4, "bn_bwd: workspace too small");
+    HS_REQUIRE(p->ws && p->ws_bytes >= (long long)g.gy * C * 2 * 4 + 3ll * C * 4, "bn_bwd: workspace too small");
+    float* coef = (float*)p->ws + (long long)g.gy * C * 2;
     hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(g.gx, g.gy), dim3(256), 0, s, (const T*)p->dy, (const T*)p->y,
                        (const T*)p->x, p->save_mean, p->save_invstd, M, C, g.tpc, p->relu, (float*)p->ws);
     HS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, (const float*)p->ws, g.gy, C,
-                       p->dbeta, p->dgamma);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, (const float*)p->ws, g.gy, C, p->gamma,
+                       p->save_mean, p->save_invstd, 1.f / (float)M, p->training, p->dbeta, p->dgamma, coef);
     HS_LAUNCH_CHECK();
     if (p->dx) {
         const long long nch = M * C / E;
         const int blocks = (int)std::min<long long>((nch + 255) / 256, 4096);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(blocks), dim3(256), 0, s, (const T*)p->dy, (const T*)p->y,
-                           (const T*)p->x, p->save_mean, p->save_invstd, p->gamma, p->dbeta, p->dgamma, (T*)p->dx,
-                           (T*)p->dres, nch, C / E, 1.f / (float)M, p->relu, p->training);
+                           (const T*)p->x, coef, (T*)p->dx, (T*)p->dres, nch, C / E, C, p->relu);
         HS_LAUNCH_CHECK();
     }
     return HS_OK;
@@ -345,7 +384,7 @@ int bn_bwd(const hs_bn_bwd_params* p, hipStream_t s) {
 }
 long long bn_ws_bytes(long long M, int C, int dtype) {
     ColGeom g = col_geom(M, C, dtype == HS_BF16 ? 8 : 4);
-    return (long long)g.gy * C * 3 * 4;
+    return (long long)g.gy * C * 3 * 4 + 3ll * C * 4;   // partials (3 floats/channel/row block) + bwd coefficients
 }
 
 // ============================================================================================
@@ -473,22 +512,40 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         }
     }
 }
-__global__ void ln_bwd_final_kernel(const float* __restrict__ ws, int nw, int H, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= H) return;
+__global__ __launch_bounds__(256) void ln_bwd_final_kernel(const float* __restrict__ ws, int nw, int H,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    // block = 64 columns x 4 row groups: coalesced 256-byte row segments, 4 partial sums merged through LDS
+    __shared__ float sa[4][64], sb[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float a = 0.f, b = 0.f;
-    for (int w = 0; w < nw; ++w) {
-        a += ws[((long long)w * 2 + 0) * H + c];
-        b += ws[((long long)w * 2 + 1) * H + c];
+    if (c < H) {
+        int w = rg;
+        for (; w + 12 < nw; w += 16) {   // 4 independent loads in flight per accumulator
+            const float a0 = ws[((long long)w * 2 + 0) * H + c], a1 = ws[((long long)(w + 4) * 2 + 0) * H + c];
+            const float a2 = ws[((long long)(w + 8) * 2 + 0) * H + c], a3 = ws[((long long)(w + 12) * 2 + 0) * H + c];
+            const float b0 = ws[((long long)w * 2 + 1) * H + c], b1 = ws[((long long)(w + 4) * 2 + 1) * H + c];
+            const float b2 = ws[((long long)(w + 8) * 2 + 1) * H + c], b3 = ws[((long long)(w + 12) * 2 + 1) * H + c];
+            a += (a0 + a1) + (a2 + a3);
+            b += (b0 + b1) + (b2 + b3);
+        }
+        for (; w < nw; w += 4) {
+            a += ws[((long long)w * 2 + 0) * H + c];
+            b += ws[((long long)w * 2 + 1) * H + c];
+        }
     }
-    dgamma[c] = a;
-    dbeta[c] = b;
+    sa[rg][cl] = a;
+    sb[rg][cl] = b;
+    __syncthreads();
+    if (rg == 0 && c < H) {
+        dgamma[c] = (sa[0][cl] + sa[1][cl]) + (sa[2][cl] + sa[3][cl]);
+        dbeta[c] = (sb[0][cl] + sb[1][cl]) + (sb[2][cl] + sb[3][cl]);
+    }
 }
 
 static int ln_bwd_blocks(long long M) {
     long long b = (M + 15) / 16;   // >= 4 rows per wave
-    if (b > 256) b = 256;
+    if (b > 128) b = 128;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -514,7 +571,7 @@ static int ln_bwd_t(const void* dy, const void* x, const float* gamma, const flo
     hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3(blocks), dim3(256), 0, s, (const T*)dy, (const T*)x, gamma, mean, rstd,
                        (T*)dx, ws, M, H);
     HS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3(ceil_div(H, 256)), dim3(256), 0, s, ws, blocks * 4, H, dgamma, dbeta);
+    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3(ceil_div(H, 64)), dim3(256), 0, s, ws, blocks * 4, H, dgamma, dbeta);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
