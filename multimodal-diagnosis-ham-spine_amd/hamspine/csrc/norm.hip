@@ -255,8 +255,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
         }
     }
 }
-// dx = ca*dz + cb*x + cc per channel:  train  ca = g*is, cb = -g*is*is*dgamma/M, cc = -ca*dbeta/M - cb*mean
-//                                      eval   ca = g*is, cb = 0, cc = 0
+// dx = ca*dz + cb*(x - mean) + cc per channel:  train  ca = g*is, cb = -g*is*is*dgamma/M, cc = -ca*dbeta/M
+//                                               eval   ca = g*is, cb = 0, cc = 0
+// (x - mean is formed first: folding mean into cc cancels catastrophically when |mean| >> std)
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ ws, int gy, int C,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, float invM, int train,
@@ -278,10 +279,11 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
     const float g = gamma ? gamma[c] : 1.f, is = invstd[c];
     const float ca = g * is;
     const float cb = train ? -ca * is * b * invM : 0.f;
-    const float cc = train ? -ca * a * invM - cb * mean[c] : 0.f;
+    const float cc = train ? -ca * a * invM : 0.f;
     coef[c] = ca;
     coef[C + c] = cb;
     coef[2 * C + c] = cc;
+    coef[3 * C + c] = mean[c];
 }
 // backward stage 2: dx = ca*dz + cb*x + cc (coefficients from bn_bwd_final_kernel); optional dres = dz
 template <typename T>
@@ -292,26 +294,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     constexpr int E = Chunk<T>::N;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long long)gridDim.x * 256) {
         const int c0 = (int)(i % cg) * E;
-        float g[E], xv[E], yv[E], o[E], ca[E], cb[E], cc[E];
+        float g[E], xv[E], yv[E], o[E], ca[E], cb[E], cc[E], mu[E];
         Chunk<T>::unpack(*(const u32x4*)(dy + i * E), g);
         Chunk<T>::unpack(*(const u32x4*)(x + i * E), xv);
         if (relu) Chunk<T>::unpack(*(const u32x4*)(y + i * E), yv);
 #pragma unroll
         for (int e = 0; e < E; e += 4) {
             const f32x4 a = *(const f32x4*)(coef + c0 + e), b = *(const f32x4*)(coef + C + c0 + e),
-                        c = *(const f32x4*)(coef + 2 * C + c0 + e);
+                        c = *(const f32x4*)(coef + 2 * C + c0 + e), m = *(const f32x4*)(coef + 3 * C + c0 + e);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 ca[e + j] = a[j];
                 cb[e + j] = b[j];
                 cc[e + j] = c[j];
+                mu[e + j] = m[j];
             }
         }
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const float dz = (relu && !(yv[e] > 0.f)) ? 0.f : g[e];
             g[e] = dz;
-            o[e] = ca[e] * dz + cb[e] * xv[e] + cc[e];
+            o[e] = ca[e] * dz + cb[e] * (xv[e] - mu[e]) + cc[e];
         }
         *(u32x4*)(dx + i * E) = Chunk<T>::pack(o);
         if (dres) *(u32x4*)(dres + i * E) = Chunk<T>::pack(g);
@@ -356,7 +359,7 @@ static int bn_bwd_t(const hs_bn_bwd_params* p, hipStream_t s) {
     const long long M = p->M;
     const int C = p->C;
     ColGeom g = col_geom(M, C, E);
-    HS_REQUIRE(p->ws && p->ws_bytes >= (long long)g.gy * C * 2 * 4 + 3ll * C * 4, "bn_bwd: workspace too small");
+    HS_REQUIRE(p->ws && p->ws_bytes >= (long long)g.gy * C * 2 * 4 + 4ll * C * 4, "bn_bwd: workspace too small");
     float* coef = (float*)p->ws + (long long)g.gy * C * 2;
     hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(g.gx, g.gy), dim3(256), 0, s, (const T*)p->dy, (const T*)p->y,
                        (const T*)p->x, p->save_mean, p->save_invstd, M, C, g.tpc, p->relu, (float*)p->ws);
@@ -384,7 +387,7 @@ int bn_bwd(const hs_bn_bwd_params* p, hipStream_t s) {
 }
 long long bn_ws_bytes(long long M, int C, int dtype) {
     ColGeom g = col_geom(M, C, dtype == HS_BF16 ? 8 : 4);
-    return (long long)g.gy * C * 3 * 4 + 3ll * C * 4;   // partials (3 floats/channel/row block) + bwd coefficients
+    return (long long)g.gy * C * 3 * 4 + 4ll * C * 4;   // partials (3 floats/channel/row block) + bwd coefficients
 }
 
 // ============================================================================================
