@@ -58,6 +58,8 @@ static void prof_end(hipStream_t s, ProfRec& r) {
     g_prof.push_back(r);
 }
 
+static int g_dbg_cfg = -1, g_dbg_ablate = 0;   // measurement overrides (hs_gemm_debug)
+
 static int combo_of(int ak, int bk) {
     if (ak == HS_A_KC && bk == HS_B_KC) return 0;
     if (ak == HS_A_KC && bk == HS_B_RC) return 1;
@@ -192,6 +194,8 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
             cfg = (vec && t128 >= 200) ? CFG_128x128 : CFG_64x64;
         }
     }
+    if (g_dbg_cfg >= 0 && cfg != CFG_STEM) cfg = g_dbg_cfg;
+    a.ablate = g_dbg_ablate;
     int BM = 64, BN = 64;
     if (cfg == CFG_128x128) { BM = 128; BN = 128; }
     else if (cfg == CFG_128x64 || cfg == CFG_STEM) { BM = 128; BN = 64; }
@@ -227,6 +231,10 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
 }  // namespace hs
 
 extern "C" {
+void hs_gemm_debug(int32_t cfg_override, int32_t ablate) {
+    hs::g_dbg_cfg = cfg_override;
+    hs::g_dbg_ablate = ablate;
+}
 void hs_prof_enable(int32_t on) {
     std::lock_guard<std::mutex> lk(hs::g_prof_mu);
     hs::g_prof_on = on != 0;

@@ -53,6 +53,7 @@ struct GemmArgs {
     int ldm;
     int accumulate;
     int vec_store;             // 1: N%4==0 and all row strides/bases allow 4-wide accesses
+    int ablate;                // measurement builds only: 1 = no global loads after tile 0, 2 = no MFMA
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
-        if (t + 1 < ntiles) stage_load(kbeg + (t + 1) * BK);
+        if (t + 1 < ntiles && !(a.ablate & 1)) stage_load(kbeg + (t + 1) * BK);
         const char* sa = smem + cur * STAGE;
         const char* sb = sa + A_BYTES;
 #pragma unroll
@@ -537,11 +538,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
                     bfr[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                 }
             }
+            if (a.ablate & 2) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+                for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(af[i]));
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(bfr[j]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            }
         }
         if (t + 1 < ntiles) stage_write(cur ^ 1);
         __syncthreads();

@@ -1,0 +1,105 @@
+"""Micro-benchmark of the GEMM / conv core on the shapes of the C2 step (run on the GPU box).
+   python tools/gemm_bench.py [--ablate]   -> table of TFLOP/s per shape / tile config"""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "multimodal-diagnosis-ham-spine_amd"))
+import torch  # noqa: E402
+
+from hamspine import _lib as L  # noqa: E402
+from hamspine import raw  # noqa: E402
+
+lib = L.lib()
+lib.hs_gemm_debug.argtypes = [C.c_int32, C.c_int32]
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def gemm_case(kind, M, N, K):
+    if kind == "nt":
+        A, B = torch.randn(M, K, device=DEV).to(BF), torch.randn(N, K, device=DEV).to(BF)
+        kw = dict(a_kind=L.A_KC, b_kind=L.B_KC, lda=K, ldb=K)
+    elif kind == "nn":
+        A, B = torch.randn(M, K, device=DEV).to(BF), torch.randn(K, N, device=DEV).to(BF)
+        kw = dict(a_kind=L.A_KC, b_kind=L.B_RC, lda=K, ldb=N)
+    else:
+        A, B = torch.randn(K, M, device=DEV).to(BF), torch.randn(K, N, device=DEV).to(BF)
+        kw = dict(a_kind=L.A_RC, b_kind=L.B_RC, lda=M, ldb=N)
+    D = torch.empty(M, N, device=DEV, dtype=torch.float32 if kind == "tn" else BF)
+    return lambda: raw.gemm(A, B, D, M, N, K, **kw)
+
+
+def conv_case(mode, N, Cin, H, Kout, R, stride):
+    pad = R // 2
+    g = raw.conv_geom(N, H, H, Cin, Kout, R, R, stride, pad)
+    P = g.P
+    x = torch.randn(N, Cin, H, H, device=DEV).to(BF).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Kout, Cin, R, R, device=DEV).to(BF).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(N, Kout, P, P, device=DEV).to(BF).contiguous(memory_format=torch.channels_last)
+    RSC = R * R * Cin
+    if mode == "fwd":
+        y = torch.empty_like(dy)
+        return (lambda: raw.gemm(x, w, y, N * P * P, Kout, RSC, a_kind=L.A_CONV, b_kind=L.B_KC, ldb=RSC, ldd=Kout, geom=g)), 2.0 * N * P * P * Kout * RSC
+    if mode == "dgrad":
+        dx = torch.empty_like(x)
+        return (lambda: raw.gemm(dy, w, dx, N * H * H, Cin, R * R * Kout, a_kind=L.A_DGRAD, b_kind=L.B_WDGRAD, ldd=Cin, geom=g)), 2.0 * N * P * P * Kout * RSC
+    dw = torch.empty(Kout, Cin, R, R, device=DEV).contiguous(memory_format=torch.channels_last)
+    split = raw.suggest_split(Kout, RSC, N * P * P, L.HS_BF16)
+    return (lambda: raw.gemm(dy, x, dw, Kout, RSC, N * P * P, a_kind=L.A_RC, b_kind=L.B_CONV, lda=Kout, ldd=RSC, geom=g, split_k=split)), 2.0 * N * P * P * Kout * RSC
+
+
+def main():
+    ablate = "--ablate" in sys.argv
+    shapes = [("nt", 4096, 2304, 768), ("nt", 4096, 768, 768), ("nt", 4096, 3072, 768), ("nt", 4096, 768, 3072),
+              ("nn", 4096, 3072, 768), ("nn", 4096, 768, 3072), ("nn", 4096, 768, 2304),
+              ("tn", 3072, 768, 4096), ("tn", 768, 3072, 4096), ("tn", 768, 768, 4096)]
+    print(f"{'shape':34s} " + " ".join(f"{c:>12s}" for c in ("auto", "128x128", "128x64", "64x64")) + ("   [ablate: noload / nomfma @auto]" if ablate else ""))
+    for kind, M, N, K in shapes:
+        fn = gemm_case(kind, M, N, K)
+        fl = 2.0 * M * N * K
+        row = []
+        for cfg in (-1, 0, 1, 2):
+            lib.hs_gemm_debug(cfg, 0)
+            row.append(fl / timeit(fn) / 1e12)
+        extra = ""
+        if ablate:
+            ab = []
+            for bits in (1, 2, 3):
+                lib.hs_gemm_debug(-1, bits)
+                ab.append(fl / timeit(fn) / 1e12)
+            extra = "   " + " / ".join(f"{v:7.1f}" for v in ab)
+        lib.hs_gemm_debug(-1, 0)
+        print(f"{kind} M={M:6d} N={N:5d} K={K:6d}      " + " ".join(f"{v:9.1f} TF" for v in row) + extra)
+    convs = [("fwd", 32, 64, 56, 64, 3, 1), ("fwd", 32, 128, 28, 128, 3, 1), ("fwd", 32, 256, 14, 256, 3, 1), ("fwd", 32, 512, 7, 512, 3, 1),
+             ("fwd", 32, 256, 56, 64, 1, 1), ("fwd", 32, 64, 56, 256, 1, 1), ("fwd", 32, 1024, 14, 256, 1, 1),
+             ("dgrad", 32, 64, 56, 64, 3, 1), ("dgrad", 32, 256, 14, 256, 3, 1), ("dgrad", 32, 128, 56, 128, 3, 2),
+             ("wgrad", 32, 64, 56, 64, 3, 1), ("wgrad", 32, 256, 14, 256, 3, 1), ("wgrad", 32, 512, 7, 512, 3, 1)]
+    for c in convs:
+        fn, fl = conv_case(*c)
+        row = []
+        for cfg in (-1, 0, 1, 2):
+            lib.hs_gemm_debug(cfg, 0)
+            try:
+                row.append(fl / timeit(fn) / 1e12)
+            except Exception:  # noqa: BLE001
+                row.append(float("nan"))
+        lib.hs_gemm_debug(-1, 0)
+        print(f"conv {c[0]:5s} N{c[1]} C{c[2]:4d} H{c[3]:3d} K{c[4]:4d} R{c[5]} s{c[6]}   " + " ".join(f"{v:9.1f} TF" for v in row))
+
+
+if __name__ == "__main__":
+    main()
