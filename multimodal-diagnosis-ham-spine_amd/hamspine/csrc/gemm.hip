@@ -169,7 +169,13 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     if (p->b_kind == HS_B_KC || p->b_kind == HS_B_RC) vec = vec && (p->ldb % epc == 0);
     if (batch > 1) vec = vec && (p->a_bs0 % epc == 0) && (p->a_bs1 % epc == 0) && (p->b_bs0 % epc == 0) && (p->b_bs1 % epc == 0);
     if (conv) HS_REQUIRE(vec, "hs_gemm: conv operands must be 16-byte aligned");
-    if (bf16) HS_REQUIRE(vec, "hs_gemm(bf16): lda/ldb/batch strides must be multiples of 8 and bases 16-byte aligned");
+    if (bf16) {
+        HS_REQUIRE(vec, "hs_gemm(bf16): lda/ldb/batch strides must be multiples of 8 and bases 16-byte aligned");
+        // LDS-DMA moves whole 16-byte chunks: a K tail inside a chunk must be zero padding in memory
+        const int k8 = (p->K + 7) / 8 * 8;
+        if (p->a_kind == HS_A_KC) HS_REQUIRE(p->K % 8 == 0 || p->lda >= k8, "hs_gemm(bf16): A rows need K%%8==0 or zero padding to %d", k8);
+        if (p->b_kind == HS_B_KC) HS_REQUIRE(p->K % 8 == 0 || p->ldb >= k8, "hs_gemm(bf16): B rows need K%%8==0 or zero padding to %d", k8);
+    }
     // 4-wide epilogue accesses
     {
         const int oesz = a.out_f32 ? 4 : esz;

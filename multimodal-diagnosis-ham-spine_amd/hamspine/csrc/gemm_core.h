@@ -364,17 +364,36 @@ __device__ __forceinline__ void tile_from_block(const GemmArgs& a, int& tm, int&
 // ================================================================================================
 // bf16 kernel
 // ================================================================================================
+// inverse of the granule XOR of rc_off_bf16 for a physical 16-byte chunk index: which logical chunk lives there
+template <int BR>
+__device__ __forceinline__ int rc_logical_chunk(int k, int pcc) {
+    constexpr int G = BR / 16;
+    int f;
+    if constexpr (G >= 8) f = (k & 3) | (((k >> 3) & 1) << 2);
+    else f = ((k >> 1) & 1) | (((k >> 3) & 1) << 1);
+    return ((((pcc >> 1) ^ f) & (G - 1)) << 1) | (pcc & 1);
+}
+
+// Staging is LDS-DMA (buffer_load_dwordx4 ... lds): every wave instruction moves 64 x 16 B straight into a
+// linear 1 KiB run of the LDS tile, so the XOR swizzles are applied on the per-lane SOURCE address (which
+// logical chunk belongs at this LDS slot) and again on the fragment reads.  Out-of-range source offsets
+// write zeros (verified on gfx950), which is how M/N/K tails and conv padding are predicated.
+// Contract for K-contiguous operands: K % 8 == 0, or the row is zero padded up to the next multiple of 8.
 template <int BM, int BN, int BK, int AK, int BKIND, bool VEC>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
     typedef bf16_t T;
-    constexpr int EPC = 8, ESZ = 2;
+    constexpr int ESZ = 2;
     constexpr bool A_RC = a_is_rc(AK), B_RC = b_is_rc(BKIND);
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_NCH = BM * BK / 8 / 256, B_NCH = BN * BK / 8 / 256;
+    constexpr int A_NI = A_BYTES / 1024 / 4, B_NI = B_BYTES / 1024 / 4;   // DMA instructions per wave per tile
+    constexpr int CPR = BK / 8;
+    static_assert(A_NI >= 1 && B_NI >= 1, "tile too small for 4 DMA waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) char lds_char;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int g = lane >> 4, l15 = lane & 15;
     int tm, tn;
@@ -398,91 +417,65 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.A + a_boff * ESZ, (unsigned)min(a_rem, 0x7fffff00ull));
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.B + b_boff * ESZ, (unsigned)min(b_rem, 0x7fffff00ull));
 
-    // ---- per-thread staging state ------------------------------------------------------------
-    KcRow<A_RC ? HS_A_KC : AK> a_rows[A_RC ? 1 : A_NCH];
-    RcCol a_col;
-    RcCol b_col;
-    KcRow<HS_A_KC> b_rows[B_RC ? 1 : B_NCH];
-    constexpr int CPR = BK / 8;
-    if constexpr (!A_RC) {
+    // ---- per-thread staging state: one LDS slot per DMA instruction ---------------------------
+    // slot s = (wave*NI + i)*64 + lane.  K-contiguous tile: row = s / CPR, physical chunk = s % CPR.
+    // Row-contiguous tile [BK][BR]: k = s / (BR/8), physical chunk = s % (BR/8).
+    KcRow<A_RC ? HS_A_KC : AK> a_rows[A_RC ? 1 : A_NI];
+    KcRow<HS_A_KC> b_rows[B_RC ? 1 : B_NI];
+    RcCol a_cols[A_RC ? A_NI : 1], b_cols[B_RC ? B_NI : 1];
+    int a_kl[A_NI], b_kl[B_NI];   // KC: logical k-chunk (x8) of the slot; RC: local k row of the slot
 #pragma unroll
-        for (int i = 0; i < A_NCH; ++i) kc_row_setup<AK>(a, m0 + (tid + 256 * i) / CPR, a_rows[i]);
-    } else {
-        rc_col_setup<AK, true>(a, m0 + (tid % (BM / 8)) * 8, a_col);
+    for (int i = 0; i < A_NI; ++i) {
+        const int s = (wave * A_NI + i) * 64 + lane;
+        if constexpr (!A_RC) {
+            const int r = s / CPR;
+            kc_row_setup<AK>(a, m0 + r, a_rows[i]);
+            constexpr int RPB = 16 / CPR;
+            a_kl[i] = ((s % CPR) ^ ((r / RPB) % CPR)) * 8;
+        } else {
+            const int k = s / (BM / 8);
+            a_kl[i] = k;
+            rc_col_setup<AK, true>(a, m0 + rc_logical_chunk<BM>(k, s % (BM / 8)) * 8, a_cols[i]);
+        }
     }
-    if constexpr (!B_RC) {
 #pragma unroll
-        for (int i = 0; i < B_NCH; ++i) {
-            const int n = n0 + (tid + 256 * i) / CPR;
+    for (int i = 0; i < B_NI; ++i) {
+        const int s = (wave * B_NI + i) * 64 + lane;
+        if constexpr (!B_RC) {
+            const int r = s / CPR;
+            const int n = n0 + r;
             b_rows[i].valid = n < a.N;
             b_rows[i].base = n * a.ldb;
             b_rows[i].hb = b_rows[i].wb = 0;
+            constexpr int RPB = 16 / CPR;
+            b_kl[i] = ((s % CPR) ^ ((r / RPB) % CPR)) * 8;
+        } else {
+            const int k = s / (BN / 8);
+            b_kl[i] = k;
+            rc_col_setup<BKIND, false>(a, n0 + rc_logical_chunk<BN>(k, s % (BN / 8)) * 8, b_cols[i]);
         }
-    } else {
-        rc_col_setup<BKIND, false>(a, n0 + (tid % (BN / 8)) * 8, b_col);
     }
 
-    u32x4 a_reg[A_NCH], b_reg[B_NCH];
-
-    auto stage_load = [&](int k0) {
-        // uniform tap decomposition for conv kinds (BK divides the channel count)
+    auto stage_dma = [&](int buf, int k0) {
         KTile kta = {0, 0, 0}, ktb = {0, 0, 0};
         if constexpr (AK == HS_A_CONV) kta = ktile_rsc(k0, a.g.C, a.g.S);
         if constexpr (AK == HS_A_DGRAD) kta = ktile_rsc(k0, a.g.K, a.g.S);
         if constexpr (BKIND == HS_B_WDGRAD) ktb = ktile_rsc(k0, a.g.K, a.g.S);
+        lds_char* la = (lds_char*)(smem) + buf * STAGE + wave * (A_NI * 1024);
+        lds_char* lb = (lds_char*)(smem) + buf * STAGE + A_BYTES + wave * (B_NI * 1024);
 #pragma unroll
-        for (int i = 0; i < A_NCH; ++i) {
-            const int id = tid + 256 * i;
+        for (int i = 0; i < A_NI; ++i) {
             unsigned off;
-            int nvalid = 8;
-            if constexpr (!A_RC) {
-                const int k = k0 + (id % CPR) * 8;
-                off = kc_chunk_off<AK, ESZ>(a, a_rows[i], kta, k, kend);
-                nvalid = kend - k;
-            } else {
-                const int k = k0 + id / (BM / 8);
-                off = rc_chunk_off<AK, true, ESZ>(a, a_col, kta, k, kend);
-                if constexpr (!VEC) nvalid = a.M - a_col.base;
-            }
-            a_reg[i] = load_chunk<T>(rsA, off, VEC, nvalid);
-            if constexpr (!A_RC && VEC) if (nvalid < 8 && nvalid > 0) mask_tail<T>(a_reg[i], nvalid);
+            if constexpr (!A_RC) off = kc_chunk_off<AK, ESZ>(a, a_rows[i], kta, k0 + a_kl[i], kend);
+            else off = rc_chunk_off<AK, true, ESZ>(a, a_cols[i], kta, k0 + a_kl[i], kend);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(la + i * 1024), 16, off, 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < B_NCH; ++i) {
-            const int id = tid + 256 * i;
+        for (int i = 0; i < B_NI; ++i) {
             unsigned off;
-            int nvalid = 8;
-            if constexpr (!B_RC) {
-                const int k = k0 + (id % CPR) * 8;
-                off = kc_chunk_off<HS_A_KC, ESZ>(a, b_rows[i], ktb, k, kend);
-                nvalid = kend - k;
-            } else {
-                const int k = k0 + id / (BN / 8);
-                off = rc_chunk_off<BKIND, false, ESZ>(a, b_col, ktb, k, kend);
-                if constexpr (!VEC) nvalid = a.N - (n0 + (tid % (BN / 8)) * 8);
-            }
-            b_reg[i] = load_chunk<T>(rsB, off, VEC, nvalid);
-            if constexpr (!B_RC && VEC) if (nvalid < 8 && nvalid > 0) mask_tail<T>(b_reg[i], nvalid);
-        }
-    };
-    auto stage_write = [&](int buf) {
-        char* sa = smem + buf * STAGE;
-        char* sb = sa + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < A_NCH; ++i) {
-            const int id = tid + 256 * i;
-            int off;
-            if constexpr (!A_RC) off = kc_off_bf16<BK>(id / CPR, id % CPR);
-            else off = rc_off_bf16<BM>(id / (BM / 8), (id % (BM / 8)) * 8);
-            *(u32x4*)(sa + off) = a_reg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_NCH; ++i) {
-            const int id = tid + 256 * i;
-            int off;
-            if constexpr (!B_RC) off = kc_off_bf16<BK>(id / CPR, id % CPR);
-            else off = rc_off_bf16<BN>(id / (BN / 8), (id % (BN / 8)) * 8);
-            *(u32x4*)(sb + off) = b_reg[i];
+            if constexpr (!B_RC) off = kc_chunk_off<HS_A_KC, ESZ>(a, b_rows[i], ktb, k0 + b_kl[i], kend);
+            else off = rc_chunk_off<BKIND, false, ESZ>(a, b_cols[i], ktb, k0 + b_kl[i], kend);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(lb + i * 1024), 16, off, 0, 0, 0);
         }
     };
 
@@ -493,16 +486,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ntiles = (kend - kbeg + BK - 1) / BK;
-    if (ntiles > 0) {
-        stage_load(kbeg);
-        stage_write(0);
-    }
+    if (ntiles > 0) stage_dma(0, kbeg);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
-        if (t + 1 < ntiles && !(a.ablate & 1)) stage_load(kbeg + (t + 1) * BK);
+        // buffer cur^1 was last read in iteration t-1, which every wave left through the barrier below
+        if (t + 1 < ntiles && !(a.ablate & 1)) stage_dma(cur ^ 1, kbeg + (t + 1) * BK);
         const char* sa = smem + cur * STAGE;
         const char* sb = sa + A_BYTES;
 #pragma unroll
@@ -551,8 +542,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
             }
         }
-        if (t + 1 < ntiles) stage_write(cur ^ 1);
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA of tile t+1 has landed (this wave's part)
+        __syncthreads();                                   // ... and everyone else's; tile t is no longer read
     }
 
     // ---- epilogue: lane owns m = .. + l15, n = .. + 4g + {0..3} ---------------------------------
