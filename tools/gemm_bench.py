@@ -18,15 +18,22 @@ DEV = "cuda"
 BF = torch.bfloat16
 
 
+lib.hs_prof_enable.argtypes = [C.c_int32]
+lib.hs_prof_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+
+
 def timeit(fn, iters=20):
+    """device-side duration of the main GEMM kernel (HIP events around each launch), seconds"""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    fl, ms, cnt = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_int64 * 4)()
+    lib.hs_prof_enable(1)
     for _ in range(iters):
         fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / iters
+    lib.hs_prof_collect(fl, ms, cnt)
+    lib.hs_prof_enable(0)
+    return sum(ms) / max(sum(cnt), 1) * 1e-3
 
 
 def gemm_case(kind, M, N, K):
