@@ -102,6 +102,10 @@ typedef struct hs_gemm_params {
     const void* mul_src;     /* u (GELU input) or y (ReLU output); same type as A, ld = ldm     */
     int32_t ldm;
     int32_t accumulate;      /* 1: D += result (f32 outputs only)                               */
+    /* segmented output (optional): rows [i*seg_rows, (i+1)*seg_rows) go to D_seg[i-1] for i = 1, 2 (row index
+       rebased), rows below seg_rows to D.  Lets one GEMM write three parameter gradients (fused QKV wgrad). */
+    int32_t seg_rows;
+    void* D_seg[2];
 } hs_gemm_params;
 
 hs_status hs_gemm(const hs_gemm_params* p, void* stream);

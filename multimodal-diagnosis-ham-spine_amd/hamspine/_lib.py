@@ -51,6 +51,7 @@ class GemmParams(C.Structure):
         ("dropout_p", f32), ("dropout_seed", u64),
         ("mul_mode", i32), ("mul_src", vp), ("ldm", i32),
         ("accumulate", i32),
+        ("seg_rows", i32), ("D_seg", vp * 2),
     ]
 
 

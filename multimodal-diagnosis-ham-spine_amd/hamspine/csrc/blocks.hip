@@ -819,10 +819,32 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
     HS_PROPAGATE(attention_bwd_run(r, a, qkv, qkv ? qkv + (long long)Hd * es : nullptr, qkv ? qkv + 2ll * Hd * es : nullptr,
                                    dctx, dq, dq ? dq + (long long)Hd * es : nullptr, dq ? dq + 2ll * Hd * es : nullptr));
     // ---- QKV projection ----
-    const hs_linear* lins[3] = {&d.q, &d.k, &d.v};
-    for (int i = 0; i < 3; ++i) {
-        hs_linear li = *lins[i];
-        HS_PROPAGATE(linear_wgrad_run(r, x, M, Hd, li, dq ? dq + (long long)i * Hd * es : nullptr, 3 * Hd));
+    // one GEMM for the three weight gradients: [dWq; dWk; dWv] = dqkv^T x, rows routed to the three tensors
+    if (d.q.dw && d.k.dw && d.v.dw) {
+        hs_gemm_params p = gemm_defaults(r.dt);
+        p.a_kind = HS_A_RC; p.b_kind = HS_B_RC;
+        p.M = 3 * Hd; p.N = Hd; p.K = (int)M;
+        p.A = dqkv; p.B = x;
+        p.a_elems = M * 3 * Hd;
+        p.b_elems = M * Hd;
+        p.lda = 3 * Hd; p.ldb = Hd;
+        p.D = d.q.dw; p.ldd = Hd; p.out_dtype = HS_F32;
+        p.seg_rows = Hd;
+        p.D_seg[0] = d.k.dw;
+        p.D_seg[1] = d.v.dw;
+        HS_PROPAGATE(gemm_splitk(r, p));
+        const hs_linear* lins[3] = {&d.q, &d.k, &d.v};
+        for (int i = 0; i < 3; ++i) {
+            hs_linear li = *lins[i];
+            li.dw = nullptr;   // bias gradients only
+            HS_PROPAGATE(linear_wgrad_run(r, x, M, Hd, li, dq ? dq + (long long)i * Hd * es : nullptr, 3 * Hd));
+        }
+    } else {
+        const hs_linear* lins[3] = {&d.q, &d.k, &d.v};
+        for (int i = 0; i < 3; ++i) {
+            hs_linear li = *lins[i];
+            HS_PROPAGATE(linear_wgrad_run(r, x, M, Hd, li, dq ? dq + (long long)i * Hd * es : nullptr, 3 * Hd));
+        }
     }
     (void)dbqkv;
     if (dx) {

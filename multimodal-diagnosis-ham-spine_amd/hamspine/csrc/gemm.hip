@@ -124,6 +124,14 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     a.mul_src = (const char*)p->mul_src;
     a.ldm = p->ldm;
     a.accumulate = p->accumulate;
+    a.seg_rows = p->seg_rows;
+    a.D_seg[0] = (char*)p->D_seg[0];
+    a.D_seg[1] = (char*)p->D_seg[1];
+    if (p->seg_rows > 0) {
+        HS_REQUIRE(batch == 1 && !p->D_preact && !p->residual && p->D_seg[0] && (p->M <= 2 * p->seg_rows || p->D_seg[1]) &&
+                       p->M <= 3 * p->seg_rows,
+                   "hs_gemm: bad segmented output");
+    }
     HS_REQUIRE(a.mul_mode == HS_MUL_NONE || a.mul_src, "hs_gemm: mul_mode without mul_src");
 
     // conv geometry
@@ -187,18 +195,15 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
         a.vec_store = vs;
     }
 
-    // tile selection: biggest tile that still gives the chip >= ~1 block per CU
+    // tile selection.  Measured on MI355X (tools/gemm_bench.py, profiles/): the GEMMs of this workload are
+    // 1-20 GFLOP, i.e. a few microseconds of MFMA time, so filling the chip evenly beats per-tile arithmetic
+    // intensity: 128x128 never wins, 128x64 wins once it yields >= ~1000 tiles, otherwise 64x64.
     if (cfg < 0) {
         const long long z = (long long)batch * split;
-        const long long t128 = (long long)ceil_div(p->M, 128) * ceil_div(p->N, 128) * z;
         const long long t12864 = (long long)ceil_div(p->M, 128) * ceil_div(p->N, 64) * z;
-        if (bf16) {
-            if (p->N > 64 && t128 >= 200) cfg = CFG_128x128;
-            else if (t12864 >= 200) cfg = CFG_128x64;
-            else cfg = CFG_64x64;
-        } else {
-            cfg = (vec && t128 >= 200) ? CFG_128x128 : CFG_64x64;
-        }
+        const long long t128 = (long long)ceil_div(p->M, 128) * ceil_div(p->N, 128) * z;
+        if (bf16) cfg = t12864 >= 1024 ? CFG_128x64 : CFG_64x64;
+        else cfg = (vec && t128 >= 200) ? CFG_128x128 : CFG_64x64;
     }
     if (g_dbg_cfg >= 0 && cfg != CFG_STEM) cfg = g_dbg_cfg;
     a.ablate = g_dbg_ablate;

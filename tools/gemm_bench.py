@@ -69,7 +69,23 @@ def conv_case(mode, N, Cin, H, Kout, R, stride):
     return (lambda: raw.gemm(dy, x, dw, Kout, RSC, N * P * P, a_kind=L.A_RC, b_kind=L.B_CONV, lda=Kout, ldd=RSC, geom=g, split_k=split)), 2.0 * N * P * P * Kout * RSC
 
 
+def deep():
+    """ablation ladder on one shape per tile config: bits 1 noload, 2 nomfma, 4 noepilogue, 8 nofragreads"""
+    for kind, M, N, K in (("nt", 4096, 2304, 768), ("nt", 4096, 768, 3072), ("tn", 3072, 768, 4096)):
+        fn = gemm_case(kind, M, N, K)
+        fl = 2.0 * M * N * K
+        for cfg, nm in ((0, "128x128"), (1, "128x64"), (2, "64x64")):
+            out = []
+            for bits in (0, 1, 2, 4, 8, 5, 9, 13, 15):
+                lib.hs_gemm_debug(cfg, bits)
+                out.append((bits, timeit(fn) * 1e6))
+            lib.hs_gemm_debug(-1, 0)
+            print(f"{kind} {M}x{N}x{K} {nm}: " + "  ".join(f"[{b}] {t:6.1f}us" for b, t in out) + f"   ideal-mfma {fl / 2.5e15 * 1e6:.1f}us")
+
+
 def main():
+    if "--deep" in sys.argv:
+        return deep()
     ablate = "--ablate" in sys.argv
     shapes = [("nt", 4096, 2304, 768), ("nt", 4096, 768, 768), ("nt", 4096, 3072, 768), ("nt", 4096, 768, 3072),
               ("nn", 4096, 3072, 768), ("nn", 4096, 768, 3072), ("nn", 4096, 768, 2304),
