@@ -205,18 +205,18 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
         if (bf16) cfg = t12864 >= 1024 ? CFG_128x64 : CFG_64x64;
         else cfg = (vec && t128 >= 200) ? CFG_128x128 : CFG_64x64;
     }
-    if (g_dbg_cfg >= 0 && cfg != CFG_STEM) cfg = g_dbg_cfg;
+    if (g_dbg_cfg >= 0 && cfg != CFG_STEM && (g_dbg_cfg < 4 || !conv)) cfg = g_dbg_cfg;
     a.ablate = g_dbg_ablate;
     int BM = 64, BN = 64;
-    if (cfg == CFG_128x128) { BM = 128; BN = 128; }
-    else if (cfg == CFG_128x64 || cfg == CFG_STEM) { BM = 128; BN = 64; }
+    if (cfg == CFG_128x128 || cfg == CFG_128x128x32) { BM = 128; BN = 128; }
+    else if (cfg == CFG_128x64 || cfg == CFG_STEM || cfg == CFG_128x64x32) { BM = 128; BN = 64; }
     a.tiles_m = ceil_div(p->M, BM);
     a.tiles_n = ceil_div(p->N, BN);
 
     a.split_k = split;
     if (split > 1) {
         HS_REQUIRE(p->splitk_ws != nullptr, "hs_gemm: split_k needs a workspace");
-        const int kb = (cfg == CFG_STEM) ? 32 : bk;
+        const int kb = (cfg == CFG_STEM || cfg == CFG_128x128x32 || cfg == CFG_128x64x32) ? 32 : bk;
         const int ktiles = ceil_div(p->K, kb);
         a.k_per_split = ceil_div(ktiles, split) * kb;
         a.splitk_ws = p->splitk_ws;

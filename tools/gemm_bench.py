@@ -74,9 +74,9 @@ def deep():
     for kind, M, N, K in (("nt", 4096, 2304, 768), ("nt", 4096, 768, 3072), ("tn", 3072, 768, 4096)):
         fn = gemm_case(kind, M, N, K)
         fl = 2.0 * M * N * K
-        for cfg, nm in ((0, "128x128"), (1, "128x64"), (2, "64x64")):
+        for cfg, nm in ((0, "128x128"), (1, "128x64"), (2, "64x64"), (4, "128x128x32"), (5, "128x64x32")):
             out = []
-            for bits in (0, 1, 2, 4, 8, 5, 9, 13, 15):
+            for bits in (0, 1, 4, 13):
                 lib.hs_gemm_debug(cfg, bits)
                 out.append((bits, timeit(fn) * 1e6))
             lib.hs_gemm_debug(-1, 0)
