@@ -4,6 +4,8 @@
 // (scratch).  The same layout code runs in "plan" mode (no launches) to answer the *_query calls, so
 // sizes and pointers cannot drift apart.
 #include <algorithm>
+#include <mutex>
+#include <stdlib.h>
 #include "hs_common.h"
 
 namespace hs {
@@ -35,7 +37,71 @@ struct Run {
     int dt;
     bool plan;
     Arena saved, ws;
+    // second stream for work that is off the critical path of a backward (weight / bias gradients): it is
+    // forked behind the producers of its inputs and joined before the composite returns
+    hipStream_t side = nullptr;
+    bool side_used = false;
 };
+
+// one non-blocking side stream and a ring of events per device (events are re-recordable; every composite joins
+// before it returns, so a ring of 64 cannot wrap onto a pending event)
+static hipStream_t g_side_stream[16] = {};
+static hipEvent_t g_events[16][64] = {};
+static int g_event_next[16] = {};
+static std::mutex g_side_mu;
+static bool overlap_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("HAMSPINE_OVERLAP");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+static int side_setup(Run& r) {
+    if (r.plan || !overlap_enabled()) return HS_OK;
+    int dev = 0;
+    HS_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return HS_OK;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    if (!g_side_stream[dev]) HS_CHECK_HIP(hipStreamCreateWithFlags(&g_side_stream[dev], hipStreamNonBlocking));
+    r.side = g_side_stream[dev];
+    return HS_OK;
+}
+static int next_event(hipEvent_t* ev) {
+    int dev = 0;
+    HS_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    int& n = g_event_next[dev & 15];
+    hipEvent_t& e = g_events[dev & 15][n];
+    n = (n + 1) & 63;
+    if (!e) HS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *ev = e;
+    return HS_OK;
+}
+// run `fn` on the side stream, ordered after everything launched so far on the main stream
+template <typename F>
+static int on_side(Run& r, F fn) {
+    if (r.plan || !r.side) return fn();
+    hipEvent_t ev;
+    HS_PROPAGATE(next_event(&ev));
+    HS_CHECK_HIP(hipEventRecord(ev, r.s));
+    HS_CHECK_HIP(hipStreamWaitEvent(r.side, ev, 0));
+    hipStream_t keep = r.s;
+    r.s = r.side;
+    const int st = fn();
+    r.s = keep;
+    r.side_used = true;
+    return st;
+}
+static int side_join(Run& r) {
+    if (r.plan || !r.side || !r.side_used) return HS_OK;
+    hipEvent_t ev;
+    HS_PROPAGATE(next_event(&ev));
+    HS_CHECK_HIP(hipEventRecord(ev, r.side));
+    HS_CHECK_HIP(hipStreamWaitEvent(r.s, ev, 0));
+    r.side_used = false;
+    return HS_OK;
+}
 static void run_init(Run& r, int dt, bool plan, void* saved, long long saved_bytes, void* ws, long long ws_bytes,
                      hipStream_t s) {
     r.s = s;
@@ -84,7 +150,8 @@ static int gemm_splitk(Run& r, hs_gemm_params& p) {
         }
         HS_PROPAGATE(gemm_impl(&p, r.s));
     }
-    r.ws.release(mk);
+    // with a side stream, slabs of consecutive GEMMs may be live concurrently: keep them until the composite ends
+    if (r.plan ? !overlap_enabled() : !r.side) r.ws.release(mk);
     return HS_OK;
 }
 
@@ -265,7 +332,7 @@ static int linear_wgrad_run(Run& r, const void* x, long long M, int ldx, const h
         const long long wsb = hs_colsum_ws_bytes(M, lin.out_f);
         void* w = r.ws.alloc(wsb);
         CALL(r, hs_colsum(r.dt, dy, M, lin.out_f, ldy, lin.db, w, wsb, 0, r.s));
-        r.ws.release(mk);
+        if (r.plan ? !overlap_enabled() : !r.side) r.ws.release(mk);
     }
     return HS_OK;
 }
@@ -497,21 +564,30 @@ static int resblock_bwd_run(Run& r, const hs_resblock_desc& d, const void* x, co
         max_act = std::max<long long>(max_act, (long long)d.N * b.s.H * b.s.W * b.s.Cin);
     }
     if (d.has_ds) max_act = std::max<long long>(max_act, Mout * Cout);
-    void* gA = r.ws.alloc(max_act * es);   // gradient wrt a conv output
-    void* gB = r.ws.alloc(max_act * es);   // gradient wrt a stage input
+    // one gradient buffer per stage (no ping-pong): the weight-gradient GEMMs run on the side stream while the
+    // main stream continues with dgrad + BN backward of the next stage
+    void* g_conv[3] = {nullptr, nullptr, nullptr};   // d(conv output) of main stage i
+    void* g_in[3] = {nullptr, nullptr, nullptr};     // d(input) of main stage i (i >= 1)
+    for (int i = 0; i < d.n_main; ++i) {
+        const StageBuf& b = L.main[i];
+        g_conv[i] = r.ws.alloc((long long)d.N * b.s.P * b.s.Q * b.s.Cout * es);
+        if (i > 0) g_in[i] = r.ws.alloc((long long)d.N * b.s.H * b.s.W * b.s.Cin * es);
+    }
+    void* g_ds = d.has_ds ? r.ws.alloc(Mout * Cout * es) : nullptr;
     void* dx_ds = (d.has_ds && dx) ? r.ws.alloc((long long)d.N * d.H * d.W * d.main[0].Cin * es) : nullptr;
-    RUN_CHECK_ARENAS(r, "resblock_bwd");
+    (void)max_act;
     for (int i = 0; i < d.n_main; ++i) HS_REQUIRE(d.main[i].Cout <= 4096, "resblock: Cout > 4096");
+    HS_PROPAGATE(side_setup(r));
 
     auto bn_backward = [&](const hs_conv_bn& cb, const StageBuf& b, long long M, const void* g_out, const void* y_out,
-                           int relu, void* g_in, void* g_res) -> int {
+                           int relu, void* g_in_, void* g_res) -> int {
         hs_bn_bwd_params q;
         memset(&q, 0, sizeof(q));
         q.dtype = r.dt; q.C = cb.Cout; q.M = M;
         q.training = d.training; q.relu = relu;
         q.dy = g_out; q.y = y_out; q.x = b.c;
         q.gamma = cb.gamma; q.save_mean = b.mean; q.save_invstd = b.invstd;
-        q.dx = g_in; q.dres = g_res;
+        q.dx = g_in_; q.dres = g_res;
         q.dgamma = cb.dgamma ? cb.dgamma : scratch_pg;
         q.dbeta = cb.dbeta ? cb.dbeta : (scratch_pg ? scratch_pg + 4096 : nullptr);
         q.ws = L.bn_ws; q.ws_bytes = L.bn_ws_bytes;
@@ -520,29 +596,31 @@ static int resblock_bwd_run(Run& r, const hs_resblock_desc& d, const void* x, co
     };
 
     // last main stage: y = relu(bn(c_last) + identity)
-    HS_PROPAGATE(bn_backward(d.main[last], L.main[last], Mout, dy, y, 1, gA, dres));
+    HS_PROPAGATE(bn_backward(d.main[last], L.main[last], Mout, dy, y, 1, g_conv[last], dres));
     const void* dres_for_x = dres;   // identity shortcut: dres flows straight into dx
     if (d.has_ds) {
         // downsample branch: identity = bn(conv(x)), no ReLU
-        HS_PROPAGATE(bn_backward(d.ds, L.ds, Mout, dres, nullptr, 0, gB, nullptr));
-        if (d.ds.dw) HS_PROPAGATE(conv_wgrad_run(r, L.ds.s, gB, x, d.ds.dw));
-        if (dx) HS_PROPAGATE(conv_dgrad_run(r, L.ds.s, gB, L.ds.w_c, dx_ds, nullptr));
+        HS_PROPAGATE(bn_backward(d.ds, L.ds, Mout, dres, nullptr, 0, g_ds, nullptr));
+        if (d.ds.dw) HS_PROPAGATE(on_side(r, [&]() { return conv_wgrad_run(r, L.ds.s, g_ds, x, d.ds.dw); }));
+        if (dx) HS_PROPAGATE(conv_dgrad_run(r, L.ds.s, g_ds, L.ds.w_c, dx_ds, nullptr));
         dres_for_x = dx_ds;
     }
-    // walk the main path backwards; gA holds d(conv output of stage i)
+    // walk the main path backwards
     for (int i = last; i >= 0; --i) {
         const StageBuf& b = L.main[i];
         const void* in = i == 0 ? x : L.main[i - 1].a;
-        if (d.main[i].dw) HS_PROPAGATE(conv_wgrad_run(r, b.s, gA, in, d.main[i].dw));
+        if (d.main[i].dw) HS_PROPAGATE(on_side(r, [&]() { return conv_wgrad_run(r, b.s, g_conv[i], in, d.main[i].dw); }));
         if (i == 0) {
-            if (dx) HS_PROPAGATE(conv_dgrad_run(r, b.s, gA, b.w_c, dx, dres_for_x));
+            if (dx) HS_PROPAGATE(conv_dgrad_run(r, b.s, g_conv[i], b.w_c, dx, dres_for_x));
         } else {
-            HS_PROPAGATE(conv_dgrad_run(r, b.s, gA, b.w_c, gB, nullptr));
+            HS_PROPAGATE(conv_dgrad_run(r, b.s, g_conv[i], b.w_c, g_in[i], nullptr));
             const StageBuf& pb = L.main[i - 1];
             const long long Mp = (long long)d.N * pb.s.P * pb.s.Q;
-            HS_PROPAGATE(bn_backward(d.main[i - 1], pb, Mp, gB, pb.a, 1, gA, nullptr));
+            HS_PROPAGATE(bn_backward(d.main[i - 1], pb, Mp, g_in[i], pb.a, 1, g_conv[i - 1], nullptr));
         }
     }
+    HS_PROPAGATE(side_join(r));
+    RUN_CHECK_ARENAS(r, "resblock_bwd");
     return HS_OK;
 }
 
@@ -779,8 +857,12 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
     hs_attn_desc a = bert_attn_desc(d, r.dt);
     // the attention arenas must be laid out exactly as in the forward: saved first
     // (attention_bwd_run below re-derives P/Pd from r.saved in the same order as attention_fwd_run)
-    void* dh = r.ws.alloc(M * Hd * es);      // gradient wrt h2 / h1 (LN inputs)
-    void* dd = r.ws.alloc(M * Hd * es);      // dropout-masked copy
+    // separate buffers for the two halves (no reuse): the weight / bias gradient GEMMs run on the side stream
+    // and may still be reading a buffer while the main stream moves on with the dgrad chain
+    void* dh2 = r.ws.alloc(M * Hd * es);     // gradient wrt h2 (output-LN input)
+    void* dd2 = r.ws.alloc(M * Hd * es);     // ... after the dropout mask
+    void* dh1 = r.ws.alloc(M * Hd * es);     // gradient wrt h1 (attention-output-LN input)
+    void* dd1 = r.ws.alloc(M * Hd * es);
     void* du = r.ws.alloc(M * I * es);       // gradient wrt u
     void* dx1 = r.ws.alloc(M * Hd * es);
     void* dctx = r.ws.alloc(M * Hd * es);
@@ -788,30 +870,30 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
     const long long ln_ws_bytes = hs_layernorm_bwd_ws_bytes(M, Hd);
     float* ln_ws = (float*)r.ws.alloc(ln_ws_bytes);
     float* scratch = (float*)r.ws.alloc(2ll * Hd * 4);
-    float* dbqkv = (float*)r.ws.alloc(3ll * Hd * 4);
+    HS_PROPAGATE(side_setup(r));
 
     // ---- output LN + FFN ----
-    CALL(r, hs_layernorm_bwd(r.dt, dy, L.h2, d.ln2.gamma, L.mean2, L.rstd2, dh, d.ln2.dgamma ? d.ln2.dgamma : scratch,
+    CALL(r, hs_layernorm_bwd(r.dt, dy, L.h2, d.ln2.gamma, L.mean2, L.rstd2, dh2, d.ln2.dgamma ? d.ln2.dgamma : scratch,
                              d.ln2.dbeta ? d.ln2.dbeta : (scratch ? scratch + Hd : nullptr), ln_ws, ln_ws_bytes, M, Hd, r.s));
-    const void* g2 = dh;
+    const void* g2 = dh2;
     if (d.hidden_dropout > 0.f) {
-        CALL(r, hs_dropout(r.dt, dh, dd, M * Hd, d.hidden_dropout, d.seed * 8 + 3, r.s));
-        g2 = dd;
+        CALL(r, hs_dropout(r.dt, dh2, dd2, M * Hd, d.hidden_dropout, d.seed * 8 + 3, r.s));
+        g2 = dd2;
     }
-    HS_PROPAGATE(linear_wgrad_run(r, L.g, M, I, d.out_l, g2, Hd));
+    HS_PROPAGATE(on_side(r, [&]() { return linear_wgrad_run(r, L.g, M, I, d.out_l, g2, Hd); }));
     HS_PROPAGATE(linear_dgrad_run(r, d.out_l, L.wo, g2, M, Hd, du, I, r.dt, HS_MUL_GELU_GRAD, L.u, I, nullptr));
-    HS_PROPAGATE(linear_wgrad_run(r, L.x1, M, Hd, d.inter_l, du, I));
-    // dx1 = du Wi + dh (residual into x1)
-    HS_PROPAGATE(linear_dgrad_run(r, d.inter_l, L.wi, du, M, I, dx1, Hd, r.dt, HS_MUL_NONE, nullptr, 0, dh));
+    HS_PROPAGATE(on_side(r, [&]() { return linear_wgrad_run(r, L.x1, M, Hd, d.inter_l, du, I); }));
+    // dx1 = du Wi + dh2 (residual into x1)
+    HS_PROPAGATE(linear_dgrad_run(r, d.inter_l, L.wi, du, M, I, dx1, Hd, r.dt, HS_MUL_NONE, nullptr, 0, dh2));
     // ---- attention output LN + dense ----
-    CALL(r, hs_layernorm_bwd(r.dt, dx1, L.h1, d.ln1.gamma, L.mean1, L.rstd1, dh, d.ln1.dgamma ? d.ln1.dgamma : scratch,
+    CALL(r, hs_layernorm_bwd(r.dt, dx1, L.h1, d.ln1.gamma, L.mean1, L.rstd1, dh1, d.ln1.dgamma ? d.ln1.dgamma : scratch,
                              d.ln1.dbeta ? d.ln1.dbeta : (scratch ? scratch + Hd : nullptr), ln_ws, ln_ws_bytes, M, Hd, r.s));
-    const void* g1 = dh;
+    const void* g1 = dh1;
     if (d.hidden_dropout > 0.f) {
-        CALL(r, hs_dropout(r.dt, dh, dd, M * Hd, d.hidden_dropout, d.seed * 8 + 2, r.s));
-        g1 = dd;
+        CALL(r, hs_dropout(r.dt, dh1, dd1, M * Hd, d.hidden_dropout, d.seed * 8 + 2, r.s));
+        g1 = dd1;
     }
-    HS_PROPAGATE(linear_wgrad_run(r, L.ctx, M, Hd, d.ao, g1, Hd));
+    HS_PROPAGATE(on_side(r, [&]() { return linear_wgrad_run(r, L.ctx, M, Hd, d.ao, g1, Hd); }));
     HS_PROPAGATE(linear_dgrad_run(r, d.ao, L.wao, g1, M, Hd, dctx, Hd, r.dt, HS_MUL_NONE, nullptr, 0, nullptr));
     // ---- attention core ----
     const char* qkv = (const char*)L.qkv;
@@ -819,41 +901,39 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
     HS_PROPAGATE(attention_bwd_run(r, a, qkv, qkv ? qkv + (long long)Hd * es : nullptr, qkv ? qkv + 2ll * Hd * es : nullptr,
                                    dctx, dq, dq ? dq + (long long)Hd * es : nullptr, dq ? dq + 2ll * Hd * es : nullptr));
     // ---- QKV projection ----
-    // one GEMM for the three weight gradients: [dWq; dWk; dWv] = dqkv^T x, rows routed to the three tensors
-    if (d.q.dw && d.k.dw && d.v.dw) {
-        hs_gemm_params p = gemm_defaults(r.dt);
-        p.a_kind = HS_A_RC; p.b_kind = HS_B_RC;
-        p.M = 3 * Hd; p.N = Hd; p.K = (int)M;
-        p.A = dqkv; p.B = x;
-        p.a_elems = M * 3 * Hd;
-        p.b_elems = M * Hd;
-        p.lda = 3 * Hd; p.ldb = Hd;
-        p.D = d.q.dw; p.ldd = Hd; p.out_dtype = HS_F32;
-        p.seg_rows = Hd;
-        p.D_seg[0] = d.k.dw;
-        p.D_seg[1] = d.v.dw;
-        HS_PROPAGATE(gemm_splitk(r, p));
+    HS_PROPAGATE(on_side(r, [&]() -> int {
+        // one GEMM for the three weight gradients: [dWq; dWk; dWv] = dqkv^T x, rows routed to the three tensors
+        const bool fused = d.q.dw && d.k.dw && d.v.dw;
+        if (fused) {
+            hs_gemm_params p = gemm_defaults(r.dt);
+            p.a_kind = HS_A_RC; p.b_kind = HS_B_RC;
+            p.M = 3 * Hd; p.N = Hd; p.K = (int)M;
+            p.A = dqkv; p.B = x;
+            p.a_elems = M * 3 * Hd;
+            p.b_elems = M * Hd;
+            p.lda = 3 * Hd; p.ldb = Hd;
+            p.D = d.q.dw; p.ldd = Hd; p.out_dtype = HS_F32;
+            p.seg_rows = Hd;
+            p.D_seg[0] = d.k.dw;
+            p.D_seg[1] = d.v.dw;
+            HS_PROPAGATE(gemm_splitk(r, p));
+        }
         const hs_linear* lins[3] = {&d.q, &d.k, &d.v};
         for (int i = 0; i < 3; ++i) {
             hs_linear li = *lins[i];
-            li.dw = nullptr;   // bias gradients only
+            if (fused) li.dw = nullptr;   // bias gradients only
             HS_PROPAGATE(linear_wgrad_run(r, x, M, Hd, li, dq ? dq + (long long)i * Hd * es : nullptr, 3 * Hd));
         }
-    } else {
-        const hs_linear* lins[3] = {&d.q, &d.k, &d.v};
-        for (int i = 0; i < 3; ++i) {
-            hs_linear li = *lins[i];
-            HS_PROPAGATE(linear_wgrad_run(r, x, M, Hd, li, dq ? dq + (long long)i * Hd * es : nullptr, 3 * Hd));
-        }
-    }
-    (void)dbqkv;
+        return HS_OK;
+    }));
     if (dx) {
         hs_linear qkv_lin;
         memset(&qkv_lin, 0, sizeof(qkv_lin));
         qkv_lin.in_f = Hd; qkv_lin.out_f = 3 * Hd;
-        // dx = dqkv Wqkv + dh (residual of the attention-output LN input)
-        HS_PROPAGATE(linear_dgrad_run(r, qkv_lin, L.wqkv, dqkv, M, 3 * Hd, dx, Hd, r.dt, HS_MUL_NONE, nullptr, 0, dh));
+        // dx = dqkv Wqkv + dh1 (residual of the attention-output LN input)
+        HS_PROPAGATE(linear_dgrad_run(r, qkv_lin, L.wqkv, dqkv, M, 3 * Hd, dx, Hd, r.dt, HS_MUL_NONE, nullptr, 0, dh1));
     }
+    HS_PROPAGATE(side_join(r));
     RUN_CHECK_ARENAS(r, "bert_layer_bwd");
     return HS_OK;
 }
