@@ -1125,6 +1125,6 @@ int64_t hs_linear_bwd_ws_bytes(int64_t M, int32_t in_f, int32_t out_f, int32_t d
     const int split = hs_gemm_suggest_split(out_f, in_f, (int)M, dtype);
     const long long a = split > 1 ? align_up((long long)split * out_f * in_f * 4, 256) : 256;
     const long long b = align_up(hs_colsum_ws_bytes(M, out_f), 256);
-    return std::max(a, b) + 512;
+    return a + b + 1024;   // slabs and column-sum partials may be live together (side-stream overlap)
 }
 }
