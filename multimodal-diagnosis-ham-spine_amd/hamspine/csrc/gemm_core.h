@@ -493,20 +493,30 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // 3-deep LDS ring: while tile t is consumed, tile t+1 is landing and tile t+2 is being issued.  The wait
+    // at the top of an iteration is COUNTED (all but the newest tile's DMAs of this wave), followed by a raw
+    // barrier (a __syncthreads() would drain vmcnt to 0).  WAR: the slot refilled in iteration t was last read in
+    // iteration t-1, which every wave has left once it passed this iteration's barrier.
+    constexpr int NDMA = A_NI + B_NI;
     const int ntiles = (kend - kbeg + BK - 1) / BK;
     if (ntiles > 0) stage_dma(0, kbeg);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
+    if (ntiles > 1) stage_dma(1, kbeg + BK);
+    int cur = 0, nxt2 = 2;
     for (int t = 0; t < ntiles; ++t) {
-        const int cur = t & 1;
-        // buffer cur^1 was last read in iteration t-1, which every wave left through the barrier below
-        if (t + 1 < ntiles && !(a.ablate & 1)) stage_dma(cur ^ 1, kbeg + (t + 1) * BK);
+        if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#ifdef HS_GEMM_ABLATE
+        if (t + 2 < ntiles && !(a.ablate & 1)) stage_dma(nxt2, kbeg + (t + 2) * BK);
+#else
+        if (t + 2 < ntiles) stage_dma(nxt2, kbeg + (t + 2) * BK);
+#endif
         const char* sa = smem + cur * STAGE;
         const char* sb = sa + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8 af[FM], bfr[FN];
+#ifdef HS_GEMM_ABLATE
             if (a.ablate & 8) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i) af[i] = bf16x8{};
@@ -519,6 +529,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
                 continue;
             }
+#endif
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int r0 = wm * WM + i * 16;
@@ -549,24 +560,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
                     bfr[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                 }
             }
+#ifdef HS_GEMM_ABLATE
             if (a.ablate & 2) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(af[i]));
 #pragma unroll
                 for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(bfr[j]));
-            } else {
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                continue;
             }
+#endif
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA of tile t+1 has landed (this wave's part)
-        __syncthreads();                                   // ... and everyone else's; tile t is no longer read
+        cur = cur == 2 ? 0 : cur + 1;
+        nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
     }
 
     // ---- epilogue: lane owns m = .. + l15, n = .. + 4g + {0..3} ---------------------------------
+#ifdef HS_GEMM_ABLATE
     if (a.ablate & 4) {
         float sink = 0.f;
 #pragma unroll
@@ -576,6 +590,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
         if (sink == 12345.678f) ((float*)a.D)[0] = sink;
         return;
     }
+#endif
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * WM + i * 16 + l15;
