@@ -286,6 +286,44 @@ hs_status hs_focal_loss(const float* logits, const int64_t* labels, const float*
 hs_status hs_center_crop_resize(const float* x, float* out, int32_t N, int32_t Cc, int32_t H, int32_t W, int32_t y0,
                                 int32_t x0, int32_t ch, int32_t cw, void* stream);
 
+/* SupConLoss(temperature) on (B, D) features, mean over anchors, loss + d/d features
+   (reference scripts/train.py:23-44).  ws: hs_supcon_ws_bytes(B, D). */
+hs_status hs_supcon_loss(const float* feat, const int64_t* labels, int32_t B, int32_t D, float temperature, float* loss,
+                         float* dfeat, float* ws, void* stream);
+int64_t hs_supcon_ws_bytes(int32_t B, int32_t D);
+
+/* ------------------------------------------------------------------------------------------- */
+/* KAN layer / MoE gating pieces (reference ConNexT/models/block/kan1.py:77-165, moe.py:171-291).  */
+/* KANLinear(x) = [SiLU(x) | b_splines(x)] @ [base_weight | spline_weight*spline_scaler]^T: the     */
+/* feature / weight packing below, the contraction on hs_gemm.                                     */
+/* ------------------------------------------------------------------------------------------- */
+/* feat[b] = [SiLU(x[b,:]) | bases(x[b,0]) .. bases(x[b,in-1])], row length in*(1 + grid_size + order);
+   grid: (in, grid_size + 2*order + 1) knots. */
+hs_status hs_kan_features_fwd(const float* x, const float* grid, float* feat, int64_t B, int32_t in_f, int32_t grid_size,
+                              int32_t order, void* stream);
+hs_status hs_kan_features_bwd(const float* x, const float* grid, const float* dfeat, float* dx, int64_t B, int32_t in_f,
+                              int32_t grid_size, int32_t order, void* stream);
+/* wcat[o] = [base_w[o,:] | spline_w[o,i,:]*scaler[o,i] ...]  (scaler may be NULL), nb = grid_size + order. */
+hs_status hs_kan_pack_weight(const float* base_w, const float* spline_w, const float* scaler, float* wcat, int32_t out_f,
+                             int32_t in_f, int32_t nb, void* stream);
+hs_status hs_kan_unpack_wgrad(const float* dwcat, const float* spline_w, const float* scaler, float* d_base, float* d_spline,
+                              float* d_scaler, int32_t out_f, int32_t in_f, int32_t nb, void* stream);
+/* noisy top-k gating on clean = x@w_gate (and raw_noise = x@w_noise when noisy): gates (B,E), load-balancing loss
+   coef*(cv^2(importance)+cv^2(load)), plus everything the backward needs (p, top: (B,17) int32, z, sigma,
+   loadrow, d_imp[E], d_load[E]).  E <= 16. */
+hs_status hs_moe_gate_fwd(const float* clean, const float* raw_noise, int32_t B, int32_t E, int32_t k, int32_t noisy,
+                          float noise_eps, uint64_t seed, float coef, float* gates, float* p, int32_t* top, float* z,
+                          float* sigma, float* loadrow, float* loss, float* d_imp, float* d_load, void* stream);
+hs_status hs_moe_gate_bwd(const float* clean, const float* raw_noise, const float* p, const int32_t* top, const float* z,
+                          const float* sigma, const float* dgates, const float* g_loss, const float* d_imp,
+                          const float* d_load, int32_t B, int32_t E, int32_t k, int32_t noisy, float* d_clean, float* d_raw,
+                          void* stream);
+/* y[b,:] = sum_e gates[b,e]*outs[e][b,:] (dense form of SparseDispatcher.combine, moe.py:86-103) and its backward. */
+hs_status hs_moe_combine_fwd(const float* gates, const float* const* outs, float* y, int32_t B, int32_t E, int32_t O,
+                             void* stream);
+hs_status hs_moe_combine_bwd(const float* gates, const float* const* outs, const float* dy, float* const* douts,
+                             float* dgates, int32_t B, int32_t E, int32_t O, void* stream);
+
 /* ------------------------------------------------------------------------------------------- */
 /* Composite executors: one call = one nn.Module forward (or backward) of the reference's module  */
 /* tree, launched from C++ so the Python host issues O(10) calls per step instead of O(1000).     */

@@ -365,8 +365,13 @@ __device__ __forceinline__ void tile_from_block(const GemmArgs& a, int& tm, int&
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    tm = id / a.tiles_n;
-    tn = id - tm * a.tiles_n;
+    if (a.ablate & 16) {          // experiment: m fastest (the B panel of a few n tiles stays in the XCD's L2)
+        tn = id / a.tiles_m;
+        tm = id - tn * a.tiles_m;
+    } else {
+        tm = id / a.tiles_n;
+        tn = id - tm * a.tiles_n;
+    }
 }
 
 // ================================================================================================

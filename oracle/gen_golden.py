@@ -145,6 +145,23 @@ def gen_ibfa():
     save("kl_divergence", p=p, q=q, kl=att.compute_kl_divergence(p, q))
 
 
+def gen_kan_moe():
+    """reference ConNexT/models/block/{kan1,moe}.py run directly (namespace-package import)"""
+    from ConNexT.models.block import kan1, moe
+    x = rnd((6, 16), 51, 0.7)
+    run_case("kan_linear", kan1.KANLinear(16, 12), dict(x=x), SEED + 80)
+    run_case("kan1_stack", kan1.KAN1([16, 24, 8]), dict(x=x), SEED + 81)
+    m = moe.MoE(16, 5, num_experts=4, hidden_size=8, k=2, layers_hidden=[16, 24, 5])
+    load_procedural(m, SEED + 82)
+    m.eval()                                   # noise off: the only deterministic gating mode
+    xi = x.clone().requires_grad_(True)
+    y, aux = m(xi)
+    cot = rnd(tuple(y.shape), SEED + 83)
+    ((y * cot).sum() + 3.0 * aux).backward()
+    save("moe_eval", out=y, aux=aux, cot=cot, inp={"x": x}, gin={"x": xi.grad},
+         gw={k: p.grad for k, p in m.named_parameters() if p.grad is not None})
+
+
 def save_tiny_bert(cfg, tmp):
     from transformers import BertConfig, BertModel
     d = os.path.join(tmp, f"bert_{cfg['hidden_size']}_{cfg['num_hidden_layers']}")
@@ -234,6 +251,7 @@ def main():
         gen_fusion()
         gen_heads()
         gen_ibfa()
+        gen_kan_moe()
         gen_bert(tmp)
         gen_e2e_baseline(tmp)
         gen_e2e_mibf(tmp)

@@ -20,6 +20,8 @@ def procedural_tensor(name, like, seed):
     g = _gen(name, seed)
     shape = tuple(like.shape)
     leaf = name.rsplit(".", 1)[-1]
+    if leaf in ("grid", "mean", "std"):          # KAN knot grid / MoE Normal(mean, std) buffers keep their values
+        return like.clone()
     if leaf == "num_batches_tracked":
         return torch.zeros(shape, dtype=like.dtype)
     if leaf == "running_var":

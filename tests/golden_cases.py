@@ -46,6 +46,11 @@ def _p():
     return fb, gt, hd, tb, att
 
 
+def _kan():
+    from ConNexT.models.block import kan1
+    return kan1
+
+
 def call_fusion(m, inp):
     if "img" in inp:
         return m(inp["img"], inp["txt"], inp["mask"])
@@ -77,6 +82,9 @@ MODULE_CASES = {
     "ibfa_h1": (SEED + 60, lambda: _o().OCrossAttnV2(64, 1), lambda: _p()[4].MultiHeadCrossAttention_v2(64, 1), call_kwargs),
     "ibfa_h4": (SEED + 61, lambda: _o().OCrossAttnV2(64, 4), lambda: _p()[4].MultiHeadCrossAttention_v2(64, 4), call_kwargs),
 }
+
+MODULE_CASES["kan_linear"] = (SEED + 80, lambda: _o().OKANLinear(16, 12), lambda: _kan().KANLinear(16, 12), call_kwargs)
+MODULE_CASES["kan1_stack"] = (SEED + 81, lambda: _o().OKAN1([16, 24, 8]), lambda: _kan().KAN1([16, 24, 8]), call_kwargs)
 
 _KINDS = {"concat": ("OConcatFusion", "ConcatFusionModule"), "weighted_concat": ("OWeightedConcatFusion", "WeightedConcatFusionModule"),
           "hadamard": ("OHadamardFusion", "HadamardFusionModule"), "bilinear": ("OBilinearFusion", "BilinearFusionModule")}

@@ -37,6 +37,20 @@ def test_oracle_module_matches_reference_vectors(name):
         _close(params[k].grad, g, f"{name}: grad {k}", rtol=1e-4)
 
 
+def test_oracle_moe_matches_reference_vectors():
+    fx = gc.load("moe_eval")
+    m = load_procedural(om.OMoE(16, 5, 4, 2, [16, 24, 5]), gc.SEED + 82).eval()
+    x = fx["inp"]["x"].clone().requires_grad_(True)
+    y, aux = m(x)
+    _close(y, fx["out"], "moe out")
+    _close(aux, fx["aux"], "moe aux loss")
+    ((y * fx["cot"]).sum() + 3.0 * aux).backward()
+    _close(x.grad, fx["gin"]["x"], "moe dx", rtol=1e-4)
+    params = dict(m.named_parameters())
+    for k, g in fx["gw"].items():
+        _close(params[k].grad, g, f"moe grad {k}", rtol=1e-4)
+
+
 def test_kl_divergence_vector():
     fx = gc.load("kl_divergence")
     _close(om.okl(fx["p"], fx["q"]), fx["kl"], "kl")

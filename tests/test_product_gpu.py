@@ -352,6 +352,43 @@ def test_cross_entropy_weights_and_smoothing():
         _close(zg.grad, 2.0 * zc.grad, "ce grad", 1e-4, 1e-7)
 
 
+def test_moe_eval_matches_reference_vectors():
+    from ConNexT.models.block.moe import MoE
+    fx = gc.load("moe_eval")
+    m = load_procedural(MoE(16, 5, num_experts=4, hidden_size=8, k=2, layers_hidden=[16, 24, 5]), gc.SEED + 82).to(DEV).eval()
+    x = fx["inp"]["x"].to(DEV).requires_grad_(True)
+    y, aux = m(x)
+    _close(y, fx["out"], "moe out", 1e-4)
+    _close(aux, fx["aux"], "moe aux", 1e-4)
+    ((y * fx["cot"].to(DEV)).sum() + 3.0 * aux).backward()
+    _close(x.grad, fx["gin"]["x"], "moe dx", 5e-4, 1e-6)
+    params = dict(m.named_parameters())
+    for k, g in fx["gw"].items():
+        assert params[k].grad is not None, k
+        _close(params[k].grad, g, f"moe grad {k}", 5e-4, 1e-6)
+    # training mode: noisy gating runs, is finite, and produces gradients for w_noise as well
+    m.train()
+    m.zero_grad(set_to_none=True)
+    y, aux = m(x)
+    (y.sum() + aux).backward()
+    assert torch.isfinite(y).all() and torch.isfinite(aux) and torch.isfinite(m.w_noise.grad).all()
+
+
+def test_supcon_matches_oracle():
+    from hamspine.kan import supcon_loss
+    g = torch.Generator().manual_seed(5)
+    f = torch.randn(32, 64, generator=g)
+    y = torch.randint(0, 7, (32,), generator=g)
+    fc = f.clone().requires_grad_(True)
+    ref = om.osupcon(fc, y, 0.07)
+    (ref * 0.5).backward()
+    fg = f.to(DEV).requires_grad_(True)
+    got = supcon_loss(fg, y.to(DEV), 0.07)
+    (got * 0.5).backward()
+    _close(got, ref, "supcon", 1e-5)
+    _close(fg.grad, fc.grad, "supcon grad", 1e-4, 1e-7)
+
+
 def test_focal_loss_and_entropy():
     from hamspine import small as S
     g = torch.Generator().manual_seed(1)

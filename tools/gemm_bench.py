@@ -90,7 +90,7 @@ def main():
     shapes = [("nt", 4096, 2304, 768), ("nt", 4096, 768, 768), ("nt", 4096, 3072, 768), ("nt", 4096, 768, 3072),
               ("nn", 4096, 3072, 768), ("nn", 4096, 768, 3072), ("nn", 4096, 768, 2304),
               ("tn", 3072, 768, 4096), ("tn", 768, 3072, 4096), ("tn", 768, 768, 4096)]
-    print(f"{'shape':34s} " + " ".join(f"{c:>12s}" for c in ("auto", "128x128", "128x64", "64x64")) + ("   [ablate: noload / nomfma @auto]" if ablate else ""))
+    print(f"{'shape':34s} " + " ".join(f"{c:>12s}" for c in ("auto", "128x128", "128x64", "64x64")) + ("   [m-fastest tile order @auto]" if ablate else ""))
     for kind, M, N, K in shapes:
         fn = gemm_case(kind, M, N, K)
         fl = 2.0 * M * N * K
@@ -101,7 +101,7 @@ def main():
         extra = ""
         if ablate:
             ab = []
-            for bits in (1, 2, 3):
+            for bits in (16,):
                 lib.hs_gemm_debug(-1, bits)
                 ab.append(fl / timeit(fn) / 1e12)
             extra = "   " + " / ".join(f"{v:7.1f}" for v in ab)
