@@ -293,6 +293,36 @@ hs_status hs_supcon_loss(const float* feat, const int64_t* labels, int32_t B, in
 int64_t hs_supcon_ws_bytes(int32_t B, int32_t D);
 
 /* ------------------------------------------------------------------------------------------- */
+/* ConvNeXt operators on NHWC activations (reference ConNexT/models/ourmodel.py:43,78 ->          */
+/* transformers ConvNextModel: ConvNextLayer.dwconv / layer_scale_parameter, ConvNextEmbeddings   */
+/* .patch_embeddings, ConvNextStage.downsampling_layer).                                          */
+/* ------------------------------------------------------------------------------------------- */
+/* depthwise ksize x ksize convolution (ksize in {3,5,7}), stride 1, padding ksize/2, C % 4 == 0.
+   w: f32 [C][ksize*ksize] (memory of a torch groups=C weight (C,1,k,k)); bias f32 [C] or NULL. */
+int64_t hs_dwconv_ws_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t ksize);
+hs_status hs_dwconv_fwd(int32_t dtype, const void* x, const float* w, const float* bias, void* y, int32_t N, int32_t H,
+                        int32_t W, int32_t C, int32_t ksize, void* ws, int64_t ws_bytes, void* stream);
+/* dx (optional) = correlation of dy with the flipped filter; dw [C][k*k] and db [C] (optional) are reduced
+   deterministically through ws. */
+hs_status hs_dwconv_bwd(int32_t dtype, const void* x, const float* w, const void* dy, void* dx, float* dw, float* db,
+                        int32_t N, int32_t H, int32_t W, int32_t C, int32_t ksize, void* ws, int64_t ws_bytes, void* stream);
+/* out[m][c] = res[m][c] + gamma[c] * rowscale[m / rows_per_sample] * u[m][c]; rowscale (f32, one value per sample:
+   stochastic depth keep/(1-p)) may be NULL. */
+hs_status hs_layerscale_fwd(int32_t dtype, const void* u, const float* gamma, const float* rowscale, int32_t rows_per_sample,
+                            const void* res, void* out, int64_t M, int32_t C, void* stream);
+/* du (optional) = gamma * rowscale * dy ; dgamma[c] = sum_m rowscale * dy * u. */
+hs_status hs_layerscale_bwd(int32_t dtype, const void* dy, const void* u, const float* gamma, const float* rowscale,
+                            int32_t rows_per_sample, void* du, float* dgamma, void* ws, int64_t ws_bytes, int64_t M, int32_t C,
+                            void* stream);
+int64_t hs_layerscale_ws_bytes(int64_t M, int32_t C);
+/* space-to-depth for stride == kernel convolutions: out[(n,p,q)][(r*k+s)*C + c] = x[n][p*k+r][q*k+s][c], P = H/k,
+   Q = W/k (floor), row pitch ldo >= k*k*C (extra columns zeroed); _bwd is the inverse scatter into dx (N,H,W,C). */
+hs_status hs_patchify_fwd(int32_t dtype, const void* x, void* out, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k,
+                          int32_t ldo, void* stream);
+hs_status hs_patchify_bwd(int32_t dtype, const void* dpatch, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k,
+                          int32_t ldp, void* stream);
+
+/* ------------------------------------------------------------------------------------------- */
 /* KAN layer / MoE gating pieces (reference ConNexT/models/block/kan1.py:77-165, moe.py:171-291).  */
 /* KANLinear(x) = [SiLU(x) | b_splines(x)] @ [base_weight | spline_weight*spline_scaler]^T: the     */
 /* feature / weight packing below, the contraction on hs_gemm.                                     */

@@ -193,6 +193,16 @@ def _declare(l):
     l.hs_linear_bwd.argtypes = [i32, vp, i64, i32, P(Linear), vp, vp, i32, vp, i32, i32, i32, vp, i32, vp, vp, i64, vp]
     l.hs_linear_bwd_ws_bytes.argtypes = [i64, i32, i32, i32]
     l.hs_linear_bwd_ws_bytes.restype = i64
+    l.hs_dwconv_ws_bytes.argtypes = [i32] * 5
+    l.hs_dwconv_ws_bytes.restype = i64
+    l.hs_dwconv_fwd.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp]
+    l.hs_dwconv_bwd.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp]
+    l.hs_layerscale_fwd.argtypes = [i32, vp, vp, vp, i32, vp, vp, i64, i32, vp]
+    l.hs_layerscale_bwd.argtypes = [i32, vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, i32, vp]
+    l.hs_layerscale_ws_bytes.argtypes = [i64, i32]
+    l.hs_layerscale_ws_bytes.restype = i64
+    l.hs_patchify_fwd.argtypes = [i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    l.hs_patchify_bwd.argtypes = [i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]
 
 
 def check(status, what=""):

@@ -242,19 +242,60 @@ def gen_e2e_mibf(tmp):
         e2e_store(f"e2e_mibf_{lc}", m, out["image_text"], loss, extra=dict(text=out["text"], image=out["image"]))
 
 
+CONNEXT_CFG = dict(hidden_sizes=[16, 32, 64, 1024], depths=[1, 1, 2, 1])
+
+
+def gen_convnext(tmp):
+    """HF ConvNextModel tower alone (forward + backward), then the reference's OurClassfierConvnextV2 end to end.
+    The reference hard-codes its BERT directory (ConNexT/models/BERT.py:11); the redirect below only maps that
+    literal path to the tiny local model, every other line that runs is the reference's."""
+    from transformers import BertModel, ConvNextConfig, ConvNextForImageClassification, ConvNextModel
+    cfg = ConvNextConfig(**CONNEXT_CFG)
+    m = ConvNextModel(cfg)
+    load_procedural(m, SEED + 300)
+    m.train()
+    x = rnd((3, 3, 64, 64), 301)
+    xi = x.clone().requires_grad_(True)
+    out = m(xi).last_hidden_state
+    cot = rnd(tuple(out.shape), 302)
+    (out * cot).sum().backward()
+    gw = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    save("convnext_tiny", x=x, out=out, cot=cot, dx=xi.grad, gnorm={k: g.norm() for k, g in gw.items()},
+         gw={k: g for k, g in gw.items() if g.numel() <= 20000})
+
+    cdir = os.path.join(tmp, "convnext")
+    ConvNextForImageClassification(cfg).save_pretrained(cdir)
+    bdir = save_tiny_bert(MIBF_BERT, tmp)
+    orig = BertModel.from_pretrained.__func__
+
+    def redirected(cls, path, *a, **k):
+        return orig(cls, bdir if path == "/data/QLI/BERT_pretain" else path, *a, **k)
+    BertModel.from_pretrained = classmethod(redirected)
+    try:
+        from ConNexT.models.ourmodel import OurClassfierConvnextV2
+        net = OurClassfierConvnextV2(num_labels=5, pretrained=True, pretrained_path=cdir)
+    finally:
+        BertModel.from_pretrained = classmethod(orig)
+    assert net._use_hf, "reference fell back to torchvision: the HF directory did not load"
+    load_procedural(net, SEED + 310)
+    net.train()
+    images, ids, mask, labels = synthetic_batch(3, 64, 16, MIBF_BERT["vocab_size"], 5, seed=311, min_len=3)
+    logits = net({"input_ids": ids, "attention_mask": mask, "transformed_image": images})
+    e2e_store("e2e_connext", net, logits, torch.nn.CrossEntropyLoss()(logits, labels))
+
+
 def main():
     torch.set_num_threads(8)
     from transformers import BertConfig, BertModel  # noqa: F401  (import before the stand-in exists: transformers probes torchvision)
     install_torchvision_standin()
     sys.path.insert(0, REF)
+    groups = {"fusion": lambda tmp: gen_fusion(), "heads": lambda tmp: gen_heads(), "ibfa": lambda tmp: gen_ibfa(),
+              "kan_moe": lambda tmp: gen_kan_moe(), "bert": gen_bert, "e2e_baseline": gen_e2e_baseline,
+              "e2e_mibf": gen_e2e_mibf, "convnext": gen_convnext}
+    want = sys.argv[1:] or list(groups)          # optional: regenerate only the named groups
     with tempfile.TemporaryDirectory() as tmp:
-        gen_fusion()
-        gen_heads()
-        gen_ibfa()
-        gen_kan_moe()
-        gen_bert(tmp)
-        gen_e2e_baseline(tmp)
-        gen_e2e_mibf(tmp)
+        for g in want:
+            groups[g](tmp)
 
 
 if __name__ == "__main__":

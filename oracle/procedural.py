@@ -32,7 +32,7 @@ def procedural_tensor(name, like, seed):
         return like.clone()
     if like.dim() <= 1:
         is_scale = leaf in ("weight", "gamma") and ("norm" in name.lower() or "bn" in name.lower() or ".1." in name or
-                                                     "downsample.1" in name)
+                                                     "downsample.1" in name or "downsampling_layer.0" in name)
         if is_scale:
             return 1.0 + 0.1 * torch.randn(shape, generator=g)
         return 0.05 * torch.randn(shape, generator=g)

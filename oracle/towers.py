@@ -9,6 +9,9 @@ that are absent from /root/reference:
   counts 11 689 512 / 21 797 672 / 25 557 032, torchvision state-dict key names) in tests/test_oracle_cpu.py.
 * transformers.BertModel (pinned 4.57.1; call sites encoder.py:125-131, mibf_net/bert.py:9-12).
   Pinned against the installed transformers (5.15.0) BertModel on seeded weights in tests/test_oracle_cpu.py.
+* transformers.ConvNextModel (call site ConNexT/models/ourmodel.py:43,78).  Pinned against the installed
+  transformers ConvNextModel on seeded weights in tests/test_oracle_cpu.py and, through the reference's own
+  OurClassfierConvnextV2 forward/backward, by tests/golden/e2e_connext.npz.
 """
 import math
 
@@ -169,4 +172,66 @@ class OBertModel(nn.Module):
             add = (1.0 - attention_mask[:, None, None, :].to(x.dtype)) * torch.finfo(x.dtype).min
         for layer in self.encoder.layer:
             x = layer(x, add)
+        return x
+
+
+# ---------------------------------------------------------------------------------------------------
+# ConvNeXt (transformers layout: embeddings / encoder.stages[i].{downsampling_layer,layers} / layernorm)
+# ---------------------------------------------------------------------------------------------------
+class _ChannelNorm(nn.LayerNorm):
+    """LayerNorm over C of an NCHW map"""
+
+    def forward(self, x):
+        return super().forward(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+
+
+class OConvNextLayer(nn.Module):
+    def __init__(self, dim, scale_init=1e-6):
+        super().__init__()
+        self.dwconv = nn.Conv2d(dim, dim, 7, padding=3, groups=dim)
+        self.layernorm = nn.LayerNorm(dim, eps=1e-6)
+        self.pwconv1 = nn.Linear(dim, 4 * dim)
+        self.pwconv2 = nn.Linear(4 * dim, dim)
+        self.layer_scale_parameter = nn.Parameter(scale_init * torch.ones(dim))
+
+    def forward(self, x):
+        y = self.layernorm(self.dwconv(x).permute(0, 2, 3, 1))
+        y = self.layer_scale_parameter * self.pwconv2(F.gelu(self.pwconv1(y)))
+        return x + y.permute(0, 3, 1, 2)
+
+
+class OConvNextStage(nn.Module):
+    def __init__(self, cin, cout, depth, down):
+        super().__init__()
+        self.downsampling_layer = nn.ModuleList([_ChannelNorm(cin, eps=1e-6), nn.Conv2d(cin, cout, 2, stride=2)] if down else [])
+        self.layers = nn.ModuleList([OConvNextLayer(cout) for _ in range(depth)])
+
+    def forward(self, x):
+        for m in self.downsampling_layer:
+            x = m(x)
+        for m in self.layers:
+            x = m(x)
+        return x
+
+
+class OConvNextModel(nn.Module):
+    def __init__(self, hidden_sizes=(128, 256, 512, 1024), depths=(3, 3, 27, 3), num_channels=3, patch_size=4,
+                 layer_norm_eps=1e-12):
+        super().__init__()
+        self.embeddings = _NS()
+        self.embeddings.patch_embeddings = nn.Conv2d(num_channels, hidden_sizes[0], patch_size, stride=patch_size)
+        self.embeddings.layernorm = _ChannelNorm(hidden_sizes[0], eps=1e-6)
+        self.encoder = _NS()
+        self.encoder.stages = nn.ModuleList()
+        prev = hidden_sizes[0]
+        for i, (dim, depth) in enumerate(zip(hidden_sizes, depths)):
+            self.encoder.stages.append(OConvNextStage(prev, dim, depth, down=i > 0))
+            prev = dim
+        self.layernorm = nn.LayerNorm(hidden_sizes[-1], eps=layer_norm_eps)   # pooled branch, unused by the reference
+
+    def forward(self, x):
+        """-> last_hidden_state (N, C_last, H/32, W/32)"""
+        x = self.embeddings.layernorm(self.embeddings.patch_embeddings(x))
+        for st in self.encoder.stages:
+            x = st(x)
         return x

@@ -17,6 +17,7 @@ TINY_BERT = dict(vocab_size=120, hidden_size=64, num_hidden_layers=2, num_attent
 MIBF_BERT = dict(vocab_size=200, hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=256,
                  max_position_embeddings=40, type_vocab_size=2, hidden_dropout_prob=0.0,
                  attention_probs_dropout_prob=0.0)
+CONNEXT_CFG = dict(hidden_sizes=[16, 32, 64, 1024], depths=[1, 1, 2, 1])
 LEVELS = ("layer2", "layer3", "layer4")
 
 
@@ -122,6 +123,25 @@ def e2e_inputs():
 def mibf_inputs():
     from oracle.procedural import synthetic_batch
     return synthetic_batch(4, 64, 16, MIBF_BERT["vocab_size"], 6, seed=91, min_len=3)
+
+
+def connext_inputs():
+    from oracle.procedural import synthetic_batch
+    return synthetic_batch(3, 64, 16, MIBF_BERT["vocab_size"], 5, seed=311, min_len=3)
+
+
+def save_convnext_dir(cfg, path):
+    """config.json + seeded-shape weights in HF layout for ConvNextModel.from_pretrained (product side)."""
+    import json
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(dict(cfg, model_type="convnext", hidden_act="gelu"), f)
+    from oracle.towers import OConvNextModel
+    sd = {"convnext." + k: v for k, v in OConvNextModel(**cfg).state_dict().items()}
+    sd["classifier.weight"] = torch.zeros(1000, cfg["hidden_sizes"][-1])     # ConvNextForImageClassification head: dropped
+    sd["classifier.bias"] = torch.zeros(1000)
+    torch.save(sd, os.path.join(path, "pytorch_model.bin"))
+    return path
 
 
 def e2e_forward(model, name, kw, images, ids, mask, tab):

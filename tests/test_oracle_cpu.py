@@ -137,6 +137,55 @@ def test_oracle_mibf_matches_reference_vectors(loss_class):
     assert any(k.startswith("I2Iattention") for k in nograd) and any("pooler" in k for k in nograd)
 
 
+def test_oracle_convnext_matches_reference_vectors():
+    fx = gc.load("convnext_tiny")
+    m = load_procedural(towers.OConvNextModel(**gc.CONNEXT_CFG), gc.SEED + 300).train()
+    x = fx["x"].clone().requires_grad_(True)
+    out = m(x)
+    _close(out, fx["out"], "convnext last_hidden_state", rtol=1e-4)
+    (out * fx["cot"]).sum().backward()
+    _close(x.grad, fx["dx"], "convnext dx", rtol=1e-3)
+    params = dict(m.named_parameters())
+    for k, n in fx["gnorm"].items():
+        _close(params[k].grad.norm(), n, f"convnext |grad {k}|", rtol=1e-3, atol=1e-7)
+    for k, g in fx["gw"].items():
+        _close(params[k].grad, g, f"convnext grad {k}", rtol=1e-3)
+    assert sorted(k for k, p in params.items() if p.grad is None) == ["layernorm.bias", "layernorm.weight"]
+
+
+def test_oracle_convnext_matches_installed_transformers():
+    tr = pytest.importorskip("transformers")
+    hf = tr.ConvNextModel(tr.ConvNextConfig(**gc.CONNEXT_CFG)).eval()
+    m = load_procedural(towers.OConvNextModel(**gc.CONNEXT_CFG), 11).eval()
+    hf.load_state_dict(m.state_dict(), strict=True)
+    x = torch.randn(2, 3, 96, 64, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        _close(m(x), hf(x).last_hidden_state, "oracle convnext vs transformers", rtol=1e-4)
+    # convnext-base-224 geometry: parameter count of the published model (87 566 464 without the classifier head)
+    base = towers.OConvNextModel()
+    assert sum(p.numel() for p in base.parameters()) == 87566464
+
+
+def test_oracle_connext_matches_reference_vectors():
+    fx = gc.load("e2e_connext")
+    images, ids, mask, labels = gc.connext_inputs()
+    m = load_procedural(om.OConNeXT(5, gc.MIBF_BERT, gc.CONNEXT_CFG), gc.SEED + 310).train()
+    logits = m({"input_ids": ids, "attention_mask": mask, "transformed_image": images})
+    _close(logits, fx["logits"], "connext logits", rtol=1e-4)
+    assert torch.equal(logits.argmax(1), fx["logits"].argmax(1))
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    _close(loss, fx["loss"], "connext loss", rtol=1e-4)
+    loss.backward()
+    params = dict(m.named_parameters())
+    for k, n in fx["gnorm"].items():
+        _close(params[k].grad.norm(), n, f"connext |grad {k}|", rtol=5e-3, atol=1e-7)
+    nograd = sorted(k for k, p in params.items() if p.grad is None)
+    assert nograd == sorted(str(s) for s in fx["nograd"])
+    # softmax over the single text key is identically 1: the text-side query/key convolutions get exactly zero gradient
+    for k in ("textbased_cross_attention.query_conv.weight", "textbased_cross_attention.key_conv.bias"):
+        assert float(fx["gnorm"][k]) == 0.0 and float(params[k].grad.abs().max()) == 0.0
+
+
 def test_resnet_known_answers():
     counts = {"resnet18": 11689512, "resnet34": 21797672, "resnet50": 25557032}
     for name, n in counts.items():
@@ -194,6 +243,25 @@ def test_product_state_dict_keys_match_oracle(tmp_path):
     o = om.OResnet50WithOurs(6, gc.MIBF_BERT)
     assert {k: tuple(v.shape) for k, v in pm.state_dict().items()} == {k: tuple(v.shape) for k, v in o.state_dict().items()}
     assert sum(p.numel() for p in pm.image_encoder.parameters()) == 25081664
+
+
+def test_product_convnext_keys_match_oracle(tmp_path):
+    from hamspine.nn.convnext import ConvNextConfig, ConvNextModel, convnext_base_features
+    pm = ConvNextModel(ConvNextConfig(**gc.CONNEXT_CFG))
+    o = towers.OConvNextModel(**gc.CONNEXT_CFG)
+    assert {k: tuple(v.shape) for k, v in pm.state_dict().items()} == {k: tuple(v.shape) for k, v in o.state_dict().items()}
+    assert sum(p.numel() for p in ConvNextModel(ConvNextConfig.base()).parameters()) == 87566464
+    # torchvision convnext_base().features: same parameters minus the pooled-branch LayerNorm (2 x 1024)
+    tv = convnext_base_features()
+    assert sum(p.numel() for p in tv.parameters()) == 87566464 - 2048
+    assert abs(tv[7][2].sd_prob - 0.5) < 1e-12 and tv[1][0].sd_prob == 0.0
+    from ConNexT.models.ourmodel import OurClassfierConvnextV2
+    bdir = gc.save_bert_dir(gc.MIBF_BERT, str(tmp_path / "b"))
+    cdir = gc.save_convnext_dir(gc.CONNEXT_CFG, str(tmp_path / "c"))
+    m = OurClassfierConvnextV2(num_labels=5, pretrained_path=cdir, bert_path=bdir)
+    oo = om.OConNeXT(5, gc.MIBF_BERT, gc.CONNEXT_CFG)
+    assert m._use_hf
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in oo.state_dict().items()}
 
 
 def test_product_param_counts_headline():
