@@ -111,6 +111,7 @@ def gpu_leg(args, rank, world, local_rank):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_issue = time.perf_counter() - t0     # host time to enqueue the timed steps (GPU-bound when well below dt)
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -118,7 +119,8 @@ def gpu_leg(args, rank, world, local_rank):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
     final_loss = loss.item()
-    log(f"rank {rank}: {args.steps} steps in {dt:.3f} s -> {dt / args.steps * 1e3:.2f} ms/step, loss {final_loss:.4f}")
+    log(f"rank {rank}: {args.steps} steps in {dt:.3f} s -> {dt / args.steps * 1e3:.2f} ms/step "
+        f"(host enqueue {t_issue / args.steps * 1e3:.2f} ms/step), loss {final_loss:.4f}")
 
     # ---- roofline leg: per-launch HIP events around the dominant kernel family, two extra steps ----------
     lib = L.lib()
@@ -147,6 +149,11 @@ def gpu_leg(args, rank, world, local_rank):
         "split": {"gemm": {"tflops": round(fl[0] / max(ms[0], 1e-9) / 1e9, 1), "ms_per_step": round(ms[0] / prof_steps, 3)},
                   "conv": {"tflops": round(fl[1] / max(ms[1], 1e-9) / 1e9, 1), "ms_per_step": round(ms[1] / prof_steps, 3)}},
     }
+    if args.gemm_log and rank == 0:   # per-launch table of one step (analysis aid, outside every timed region)
+        lib.hs_prof_enable(1)
+        step()
+        L.check(lib.hs_prof_dump(args.gemm_log.encode()), "hs_prof_dump")
+        lib.hs_prof_enable(0)
     return dt, final_loss, roofline, nparams
 
 
@@ -192,6 +199,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--gemm-log", default=None, help="append a per-launch CSV of one extra step to this file")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -121,6 +121,9 @@ int32_t hs_gemm_suggest_split(int32_t M, int32_t N, int32_t K, int32_t dtype);
 void hs_gemm_debug(int32_t cfg_override, int32_t ablate);
 void hs_prof_enable(int32_t on);
 hs_status hs_prof_collect(double* flops, double* ms, int64_t* launches);
+/* measurement only: append one CSV line per recorded launch (class, operand combo, tile cfg, M, N, K, batch, split_k,
+   filter R, stride, milliseconds) to `path` and clear the records. */
+hs_status hs_prof_dump(const char* path);
 
 /* ------------------------------------------------------------------------------------------- */
 /* BatchNorm2d over NHWC activations viewed as [M = N*H*W][C]                                    */

@@ -161,27 +161,34 @@ __global__ __launch_bounds__(64) void dwconv_wgrad_kernel(const T* __restrict__ 
 }
 __global__ __launch_bounds__(256) void dwconv_wgrad_final_kernel(const float* __restrict__ ws, int chunks, int C, int taps,
                                                                  float* __restrict__ dw, float* __restrict__ db) {
-    const int i = blockIdx.x * 256 + threadIdx.x;   // i = t*C + c over (taps+1)*C
-    if (i >= (taps + 1) * C) return;
-    const int t = i / C, c = i - t * C;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const size_t stride = (size_t)(taps + 1) * C;
-    int k = 0;
-    for (; k + 3 < chunks; k += 4) {
-        a0 += ws[(size_t)k * stride + i];
-        a1 += ws[(size_t)(k + 1) * stride + i];
-        a2 += ws[(size_t)(k + 2) * stride + i];
-        a3 += ws[(size_t)(k + 3) * stride + i];
+    // 64 consecutive (tap, channel) entries x 4 chunk groups per block, summed in a fixed order
+    __shared__ float sh[4][64];
+    const int il = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;   // i = t*C + c over (taps+1)*C
+    const int n = (taps + 1) * C;
+    float a0 = 0.f, a1 = 0.f;
+    if (i < n) {
+        const size_t stride = (size_t)n;
+        int k = grp;
+        for (; k + 4 < chunks; k += 8) {
+            a0 += ws[(size_t)k * stride + i];
+            a1 += ws[(size_t)(k + 4) * stride + i];
+        }
+        if (k < chunks) a0 += ws[(size_t)k * stride + i];
     }
-    for (; k < chunks; ++k) a0 += ws[(size_t)k * stride + i];
-    const float v = (a0 + a1) + (a2 + a3);
-    if (t < taps) dw[(size_t)c * taps + t] = v;
-    else if (db) db[c] = v;
+    sh[grp][il] = a0 + a1;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        const float v = (sh[0][il] + sh[1][il]) + (sh[2][il] + sh[3][il]);
+        const int t = i / C, c = i - t * C;
+        if (t < taps) dw[(size_t)c * taps + t] = v;
+        else if (db) db[c] = v;
+    }
 }
 
 static inline int dw_chunks(int N, int H, int C) {
     const int groups = (C + 63) / 64;
-    int ch = (4096 + groups - 1) / groups;
+    int ch = (2048 + groups - 1) / groups;
     return std::max(1, std::min(ch, N * H));
 }
 
@@ -230,8 +237,8 @@ static int dwconv_bwd_t(const void* x, const float* w, const void* dy, void* dx,
         else
             hipLaunchKernelGGL((dwconv_wgrad_kernel<T, 3>), grid, dim3(64), 0, s, (const T*)x, (const T*)dy, part, N, H, W, C);
         HS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(dwconv_wgrad_final_kernel, dim3(cn_grid((long long)(taps + 1) * C)), dim3(256), 0, s, part, chunks,
-                           C, taps, dw, db);
+        hipLaunchKernelGGL(dwconv_wgrad_final_kernel, dim3(cn_grid((long long)(taps + 1) * C, 64)), dim3(256), 0, s, part,
+                           chunks, C, taps, dw, db);
         HS_LAUNCH_CHECK();
     }
     return HS_OK;
@@ -281,18 +288,23 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const T* __restrict
 }
 __global__ __launch_bounds__(256) void partial_colsum_final_kernel(const float* __restrict__ ws, int gy, int C,
                                                                    float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float sh[4][64];
+    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float a0 = 0.f, a1 = 0.f;
-    int k = 0;
-    for (; k + 1 < gy; k += 2) {
-        a0 += ws[(size_t)k * C + c];
-        a1 += ws[(size_t)(k + 1) * C + c];
+    if (c < C) {
+        int k = grp;
+        for (; k + 4 < gy; k += 8) {
+            a0 += ws[(size_t)k * C + c];
+            a1 += ws[(size_t)(k + 4) * C + c];
+        }
+        if (k < gy) a0 += ws[(size_t)k * C + c];
     }
-    if (k < gy) a0 += ws[(size_t)k * C + c];
-    out[c] = a0 + a1;
+    sh[grp][cl] = a0 + a1;
+    __syncthreads();
+    if (grp == 0 && c < C) out[c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
-static inline int ls_gy(long long M) { return (int)std::min<long long>(std::max<long long>(M / 16, 1), 512); }
+static inline int ls_gy(long long M) { return (int)std::min<long long>(std::max<long long>(M / 16, 1), 256); }
 
 template <typename T>
 static int layerscale_fwd_t(const void* u, const float* gamma, const float* rowscale, int rps, const void* res, void* out,
@@ -310,7 +322,7 @@ static int layerscale_bwd_t(const void* dy, const void* u, const float* gamma, c
     hipLaunchKernelGGL(layerscale_bwd_kernel<T>, dim3((C + 255) / 256, gy), dim3(256), 0, s, (const T*)dy, (const T*)u, gamma,
                        rowscale, rps, (T*)du, ws, M, C);
     HS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(partial_colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, gy, C, dgamma);
+    hipLaunchKernelGGL(partial_colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, ws, gy, C, dgamma);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }

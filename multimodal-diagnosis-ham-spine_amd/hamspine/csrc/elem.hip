@@ -230,33 +230,81 @@ __global__ __launch_bounds__(256) void axpby_kernel(const TX* __restrict__ x, co
     }
 }
 
+// Same-type elementwise maps run on 16-byte chunks (8 bf16 / 4 f32 per lane) when every pointer is 16-byte aligned,
+// with a scalar tail; `al` is decided on the host.
+template <typename T, typename F1, typename FS>
+__device__ __forceinline__ void map1(const T* __restrict__ x, T* __restrict__ o, long long n, bool al, F1 fvec, FS fs) {
+    constexpr int V = Chunk<T>::N;
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+    const long long nv = al ? n / V : 0;
+    for (long long i = tid; i < nv; i += stride) {
+        float f[V];
+        Chunk<T>::unpack(((const u32x4*)x)[i], f);
+        fvec(i * V, f);
+        ((u32x4*)o)[i] = Chunk<T>::pack(f);
+    }
+    for (long long i = nv * V + tid; i < n; i += stride) o[i] = from_f32<T>(fs(i, to_f32(x[i])));
+}
+template <typename T, typename F2>
+__device__ __forceinline__ void map2(const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ o, long long n, bool al,
+                                     F2 f2) {
+    constexpr int V = Chunk<T>::N;
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+    const long long nv = al ? n / V : 0;
+    for (long long i = tid; i < nv; i += stride) {
+        float f[V], g[V];
+        Chunk<T>::unpack(((const u32x4*)x)[i], f);
+        Chunk<T>::unpack(((const u32x4*)y)[i], g);
+#pragma unroll
+        for (int k = 0; k < V; ++k) f[k] = f2(f[k], g[k]);
+        ((u32x4*)o)[i] = Chunk<T>::pack(f);
+    }
+    for (long long i = nv * V + tid; i < n; i += stride) o[i] = from_f32<T>(f2(to_f32(x[i]), to_f32(y[i])));
+}
+static inline bool al16(const void* a, const void* b = nullptr, const void* c = nullptr) {
+    return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
+}
+
 // elementwise dropout (forward and backward use the same (seed, index) mask)
 template <typename T>
-__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ o, long long n,
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ o, long long n, int al,
                                                       unsigned thresh, float inv_keep, unsigned long long seed) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        o[i] = from_f32<T>(to_f32(x[i]) * dropout_scale(seed, i, thresh, inv_keep));
+    constexpr int V = Chunk<T>::N;
+    map1<T>(x, o, n, al != 0,
+            [&](long long i0, float* f) {
+#pragma unroll
+                for (int h = 0; h < V / 4; ++h) {
+                    float sc[4];
+                    dropout_scale4(seed, i0 + 4 * h, thresh, inv_keep, sc);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) f[4 * h + k] *= sc[k];
+                }
+            },
+            [&](long long i, float v) { return v * dropout_scale(seed, i, thresh, inv_keep); });
 }
 
 // relu forward / backward (standalone; the fused forms live in the GEMM and BN epilogues)
 template <typename T>
-__global__ __launch_bounds__(256) void relu_kernel(const T* __restrict__ x, T* __restrict__ o, long long n) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        o[i] = from_f32<T>(fmaxf(to_f32(x[i]), 0.f));
+__global__ __launch_bounds__(256) void relu_kernel(const T* __restrict__ x, T* __restrict__ o, long long n, int al) {
+    constexpr int V = Chunk<T>::N;
+    map1<T>(x, o, n, al != 0,
+            [&](long long, float* f) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) f[k] = fmaxf(f[k], 0.f);
+            },
+            [&](long long, float v) { return fmaxf(v, 0.f); });
 }
 template <typename T>
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
-                                                       T* __restrict__ o, long long n) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        o[i] = to_f32(y[i]) > 0.f ? dy[i] : from_f32<T>(0.f);
+                                                       T* __restrict__ o, long long n, int al) {
+    map2<T>(dy, y, o, n, al != 0, [](float g, float yy) { return yy > 0.f ? g : 0.f; });
 }
 
 // dx = dy * gelu'(u)
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ u,
-                                                       T* __restrict__ o, long long n) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        o[i] = from_f32<T>(to_f32(dy[i]) * gelu_erf_grad(to_f32(u[i])));
+                                                       T* __restrict__ o, long long n, int al) {
+    map2<T>(dy, u, o, n, al != 0, [](float g, float uu) { return g * gelu_grad_t<T>(uu); });
 }
 // out = x * (*scalar)   (scalar lives on the device: no host sync in loss backward)
 __global__ __launch_bounds__(256) void mul_dev_scalar_kernel(const float* __restrict__ x, const float* __restrict__ sc,
@@ -773,19 +821,19 @@ hs_status hs_dropout(int32_t dtype, const void* x, void* out, int64_t n, float p
     const float ik = 1.f / (1.f - p);
     if (dtype == HS_BF16)
         hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
-                           (bf16_t*)out, n, th, ik, seed);
+                           (bf16_t*)out, n, (int)al16(x, out), th, ik, seed);
     else
         hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
-                           (float*)out, n, th, ik, seed);
+                           (float*)out, n, (int)al16(x, out), th, ik, seed);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
 hs_status hs_relu_fwd(int32_t dtype, const void* x, void* out, int64_t n, void* stream) {
     HS_REQUIRE(x && out, "relu: null argument");
     if (dtype == HS_BF16)
-        hipLaunchKernelGGL(relu_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, n);
+        hipLaunchKernelGGL(relu_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, n, (int)al16(x, out));
     else
-        hipLaunchKernelGGL(relu_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, n);
+        hipLaunchKernelGGL(relu_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, n, (int)al16(x, out));
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
@@ -793,10 +841,10 @@ hs_status hs_relu_bwd(int32_t dtype, const void* dy, const void* y, void* dx, in
     HS_REQUIRE(dy && y && dx, "relu_bwd: null argument");
     if (dtype == HS_BF16)
         hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
-                           (const bf16_t*)y, (bf16_t*)dx, n);
+                           (const bf16_t*)y, (bf16_t*)dx, n, (int)al16(dy, y, dx));
     else
         hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
-                           (const float*)y, (float*)dx, n);
+                           (const float*)y, (float*)dx, n, (int)al16(dy, y, dx));
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
@@ -804,10 +852,10 @@ hs_status hs_gelu_bwd(int32_t dtype, const void* dy, const void* u, void* dx, in
     HS_REQUIRE(dy && u && dx, "gelu_bwd: null argument");
     if (dtype == HS_BF16)
         hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
-                           (const bf16_t*)u, (bf16_t*)dx, n);
+                           (const bf16_t*)u, (bf16_t*)dx, n, (int)al16(dy, u, dx));
     else
         hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
-                           (const float*)u, (float*)dx, n);
+                           (const float*)u, (float*)dx, n, (int)al16(dy, u, dx));
     HS_LAUNCH_CHECK();
     return HS_OK;
 }

@@ -31,6 +31,7 @@ struct ProfRec {
     hipEvent_t a, b;
     double flops;
     int cls;
+    int M, N, K, combo, cfg, split, batch, conv_r, conv_stride;
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -49,11 +50,11 @@ static bool prof_begin(hipStream_t s, double flops, int cls, ProfRec& r) {
     }
     r.flops = flops;
     r.cls = cls;
-    hipEventRecord(r.a, s);
+    (void)hipEventRecord(r.a, s);
     return true;
 }
 static void prof_end(hipStream_t s, ProfRec& r) {
-    hipEventRecord(r.b, s);
+    (void)hipEventRecord(r.b, s);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back(r);
 }
@@ -197,12 +198,12 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
 
     // tile selection.  Measured on MI355X (tools/gemm_bench.py, profiles/): the GEMMs of this workload are
     // 1-20 GFLOP, i.e. a few microseconds of MFMA time, so filling the chip evenly beats per-tile arithmetic
-    // intensity: 128x128 never wins, 128x64 wins once it yields >= ~1000 tiles, otherwise 64x64.
+    // intensity: 128x128 never wins, 128x64 wins once it yields >= ~1500 tiles, otherwise 64x64.
     if (cfg < 0) {
         const long long z = (long long)batch * split;
         const long long t12864 = (long long)ceil_div(p->M, 128) * ceil_div(p->N, 64) * z;
         const long long t128 = (long long)ceil_div(p->M, 128) * ceil_div(p->N, 128) * z;
-        if (bf16) cfg = t12864 >= 1024 ? CFG_128x64 : CFG_64x64;
+        if (bf16) cfg = t12864 >= 1536 ? CFG_128x64 : CFG_64x64;
         else cfg = (vec && t128 >= 200) ? CFG_128x128 : CFG_64x64;
     }
     if (g_dbg_cfg >= 0 && cfg != CFG_STEM && (g_dbg_cfg < 4 || !conv)) cfg = g_dbg_cfg;
@@ -227,7 +228,11 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     const bool timed = prof_begin(stream, 2.0 * p->M * p->N * (double)p->K * batch, (bf16 ? 0 : 2) + (conv ? 1 : 0), rec);
     if (bf16) st = conv ? launch_bf16_conv(cfg, combo, a, grid, stream) : launch_bf16_plain(cfg, combo, a, grid, stream);
     else st = conv ? launch_f32_conv(cfg, combo, a, grid, stream) : launch_f32_plain(cfg, combo, vec, a, grid, stream);
-    if (timed) prof_end(stream, rec);
+    if (timed) {
+        rec.M = p->M; rec.N = p->N; rec.K = p->K; rec.combo = combo; rec.cfg = cfg; rec.split = split; rec.batch = batch;
+        rec.conv_r = conv ? p->g.R : 0; rec.conv_stride = conv ? p->g.stride : 0;
+        prof_end(stream, rec);
+    }
     HS_PROPAGATE(st);
     if (split > 1) {
         const long long work = (long long)p->M * ((p->N + 3) / 4);
@@ -269,6 +274,23 @@ hs_status hs_prof_collect(double* flops, double* ms, int64_t* launches) {
         hs::g_prof_pool.emplace_back(r.a, r.b);
     }
     hs::g_prof.clear();
+    return HS_OK;
+}
+/* Synchronises, appends one CSV line per recorded launch (cls,combo,cfg,M,N,K,batch,split,R,stride,ms) to `path`, clears. */
+hs_status hs_prof_dump(const char* path) {
+    HS_CHECK_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(hs::g_prof_mu);
+    FILE* f = fopen(path, "a");
+    HS_REQUIRE(f != nullptr, "hs_prof_dump: cannot open %s", path);
+    for (auto& r : hs::g_prof) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess)
+            fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.6f\n", r.cls, r.combo, r.cfg, r.M, r.N, r.K, r.batch, r.split, r.conv_r,
+                    r.conv_stride, t);
+        hs::g_prof_pool.emplace_back(r.a, r.b);
+    }
+    hs::g_prof.clear();
+    fclose(f);
     return HS_OK;
 }
 const char* hs_last_error(void) { return hs::last_error(); }

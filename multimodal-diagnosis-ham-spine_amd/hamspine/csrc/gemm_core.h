@@ -115,7 +115,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, long long dbase, in
         load4<T>(a.mul_src, (long long)m * a.ldm + n, vec, nvalid, u);   // mul_src is never batched
         if (a.mul_mode == HS_MUL_GELU_GRAD) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(u[j]);
+            for (int j = 0; j < 4; ++j) v[j] *= gelu_grad_t<T>(u[j]);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = u[j] > 0.f ? v[j] : 0.f;
@@ -137,12 +137,19 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, long long dbase, in
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
     } else if (a.act == HS_ACT_GELU) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+        for (int j = 0; j < 4; ++j) v[j] = gelu_fwd_t<T>(v[j]);
     }
     if (a.drop_thresh) {
         const unsigned long long e = ((unsigned long long)z * a.M + m) * (unsigned long long)a.N + n;
+        if ((e & 3) == 0) {
+            float sc[4];
+            dropout_scale4(a.drop_seed, e, a.drop_thresh, a.drop_inv_keep, sc);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= dropout_scale(a.drop_seed, e + j, a.drop_thresh, a.drop_inv_keep);
+            for (int j = 0; j < 4; ++j) v[j] *= sc[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= dropout_scale(a.drop_seed, e + j, a.drop_thresh, a.drop_inv_keep);
+        }
     }
     if (a.residual) {
         float r[4];
@@ -498,104 +505,108 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // 3-deep LDS ring: while tile t is consumed, tile t+1 is landing and tile t+2 is being issued.  The wait
-    // at the top of an iteration is COUNTED (all but the newest tile's DMAs of this wave), followed by a raw
-    // barrier (a __syncthreads() would drain vmcnt to 0).  WAR: the slot refilled in iteration t was last read in
-    // iteration t-1, which every wave has left once it passed this iteration's barrier.
+    // 3-slot LDS ring, software pipelined at two levels.
+    //  * tiles: when the waves meet at the barrier of tile t, tile t+1 has landed, tile t+2 is in flight and the
+    //    slot of tile t (whose fragment reads every wave has drained) is refilled with tile t+3.  The wait before
+    //    the barrier is COUNTED (all but the newest in-flight tile of this wave; a __syncthreads() would drain
+    //    vmcnt to 0).
+    //  * fragments: the ds_reads of k-phase p+1 (or of phase 0 of the next tile, right after the barrier) are issued
+    //    before the MFMAs of phase p, into the other half of a double-buffered fragment set, so the LDS latency
+    //    hides under 8..16 MFMAs instead of stalling every MFMA pair.
     constexpr int NDMA = A_NI + B_NI;
+    constexpr int KS = BK / 32;
     const int ntiles = (kend - kbeg + BK - 1) / BK;
-    if (ntiles > 0) stage_dma(0, kbeg);
-    if (ntiles > 1) stage_dma(1, kbeg + BK);
-    int cur = 0, nxt2 = 2;
-    for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-#ifdef HS_GEMM_ABLATE
-        if (t + 2 < ntiles && !(a.ablate & 1)) stage_dma(nxt2, kbeg + (t + 2) * BK);
-#else
-        if (t + 2 < ntiles) stage_dma(nxt2, kbeg + (t + 2) * BK);
-#endif
-        const char* sa = smem + cur * STAGE;
+
+    auto load_frags = [&](int slot, int ks, bf16x8 (&af)[FM], bf16x8 (&bfr)[FN]) {
+        const char* sa = smem + slot * STAGE;
         const char* sb = sa + A_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < BK / 32; ++ks) {
-            bf16x8 af[FM], bfr[FN];
-#ifdef HS_GEMM_ABLATE
-            if (a.ablate & 8) {
-#pragma unroll
-                for (int i = 0; i < FM; ++i) af[i] = bf16x8{};
-#pragma unroll
-                for (int j = 0; j < FN; ++j) bfr[j] = bf16x8{};
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-                continue;
+        for (int i = 0; i < FM; ++i) {
+            const int r0 = wm * WM + i * 16;
+            if constexpr (!A_RC) {
+                af[i] = *(const bf16x8*)(sa + kc_off_bf16<BK>(r0 + l15, ks * 4 + g));
+            } else {
+                const int kb = ks * 32 + 8 * g + (l15 >> 2);
+                const int col = r0 + 4 * (lane & 3);
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(sa + rc_off_bf16<BM>(kb, col)));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(sa + rc_off_bf16<BM>(kb + 4, col)));
+                af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
-#endif
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int r0 = wm * WM + i * 16;
-                if constexpr (!A_RC) {
-                    af[i] = *(const bf16x8*)(sa + kc_off_bf16<BK>(r0 + l15, ks * 4 + g));
-                } else {
-                    const int kb = ks * 32 + 8 * g + (l15 >> 2);
-                    const int col = r0 + 4 * (lane & 3);
-                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(sa + rc_off_bf16<BM>(kb, col)));
-                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(sa + rc_off_bf16<BM>(kb + 4, col)));
-                    af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int r0 = wn * WN + j * 16;
-                if constexpr (!B_RC) {
-                    bfr[j] = *(const bf16x8*)(sb + kc_off_bf16<BK>(r0 + l15, ks * 4 + g));
-                } else {
-                    const int kb = ks * 32 + 8 * g + (l15 >> 2);
-                    const int col = r0 + 4 * (lane & 3);
-                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(sb + rc_off_bf16<BN>(kb, col)));
-                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(sb + rc_off_bf16<BN>(kb + 4, col)));
-                    bfr[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                }
-            }
-#ifdef HS_GEMM_ABLATE
-            if (a.ablate & 2) {
-#pragma unroll
-                for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(af[i]));
-#pragma unroll
-                for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(bfr[j]));
-                continue;
-            }
-#endif
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
-        cur = cur == 2 ? 0 : cur + 1;
-        nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
-    }
-
-    // ---- epilogue: lane owns m = .. + l15, n = .. + 4g + {0..3} ---------------------------------
-#ifdef HS_GEMM_ABLATE
-    if (a.ablate & 4) {
-        float sink = 0.f;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int r0 = wn * WN + j * 16;
+            if constexpr (!B_RC) {
+                bfr[j] = *(const bf16x8*)(sb + kc_off_bf16<BK>(r0 + l15, ks * 4 + g));
+            } else {
+                const int kb = ks * 32 + 8 * g + (l15 >> 2);
+                const int col = r0 + 4 * (lane & 3);
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(sb + rc_off_bf16<BN>(kb, col)));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(sb + rc_off_bf16<BN>(kb + 4, col)));
+                bfr[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+        }
+    };
+    auto mma = [&](const bf16x8 (&af)[FM], const bf16x8 (&bfr)[FN]) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) sink += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (sink == 12345.678f) ((float*)a.D)[0] = sink;
-        return;
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    };
+
+    int cur = 0;   // slot of tile t
+    // tile boundary: this wave's reads of slot `cur` are complete and its DMAs of tile t+1 have landed; after the barrier
+    // so have everyone else's, and slot `cur` takes tile t+3.
+    auto next_tile = [&](int t) {
+        if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 3 < ntiles) stage_dma(cur, kbeg + (t + 3) * BK);
+        cur = cur == 2 ? 0 : cur + 1;
+    };
+
+    if (ntiles > 0) {
+        stage_dma(0, kbeg);
+        if (ntiles > 1) stage_dma(1, kbeg + BK);
+        if (ntiles > 2) stage_dma(2, kbeg + 2 * BK);
+        if (ntiles > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+        else if (ntiles > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        bf16x8 a0[FM], b0[FN], a1[FM], b1[FN];
+        load_frags(0, 0, a0, b0);
+        static_assert(KS == 1 || KS == 2, "BK must be 32 or 64");
+        if constexpr (KS == 2) {
+            for (int t = 0; t + 1 < ntiles; ++t) {
+                load_frags(cur, 1, a1, b1);
+                mma(a0, b0);
+                next_tile(t);
+                load_frags(cur, 0, a0, b0);
+                mma(a1, b1);
+            }
+            load_frags(cur, 1, a1, b1);
+            mma(a0, b0);
+            mma(a1, b1);
+        } else {
+            for (int t = 0; t + 1 < ntiles; ++t) {
+                next_tile(t);
+                load_frags(cur, 0, a1, b1);
+                mma(a0, b0);
+#pragma unroll
+                for (int i = 0; i < FM; ++i) a0[i] = a1[i];
+#pragma unroll
+                for (int j = 0; j < FN; ++j) b0[j] = b1[j];
+            }
+            mma(a0, b0);
+        }
     }
-#endif
+
+    // ---- epilogue: lane owns m = .. + l15, n = .. + 4g + {0..3} ---------------------------------
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * WM + i * 16 + l15;

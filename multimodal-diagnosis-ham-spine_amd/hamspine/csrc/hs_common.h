@@ -167,10 +167,42 @@ __device__ __forceinline__ unsigned hash_u32(unsigned long long seed, unsigned l
     z = z ^ (z >> 31);
     return (unsigned)(z >> 32);
 }
-// returns scale (0 or 1/(1-p)); thresh = p * 2^32
+// Dropout masks come in groups of four consecutive elements: one cheap 32-bit mix yields 4 x 16 uniform bits for
+// elements 4q..4q+3 (the 64-bit multiplies of hash_u32 cost ~190 issue cycles per element on the quarter-rate
+// integer multiplier; this is ~35).  keep(i) = bits16(q = i / 4, i % 4) >= thresh >> 16, i.e. p is honoured to 2^-16.
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ u32x2 dropout_bits4(unsigned long long seed, unsigned long long q) {
+    const unsigned s0 = (unsigned)seed, s1 = (unsigned)(seed >> 32);
+    const unsigned x = (unsigned)q * 0x9E3779B1u + s0 + (unsigned)(q >> 32) * 0x85EBCA77u;
+    u32x2 r;
+    r[0] = mix32(x ^ s1);
+    r[1] = mix32(r[0] + 0x6C8E9CF5u + s1);
+    return r;
+}
+// scale (0 or 1/(1-p)) of one element; thresh = p * 2^32
 __device__ __forceinline__ float dropout_scale(unsigned long long seed, unsigned long long idx,
                                                unsigned thresh, float inv_keep) {
-    return hash_u32(seed, idx) >= thresh ? inv_keep : 0.f;
+    const u32x2 b = dropout_bits4(seed, idx >> 2);
+    const unsigned w = (idx & 2) ? b[1] : b[0];
+    const unsigned f = (idx & 1) ? (w >> 16) : (w & 0xffffu);
+    return f >= (thresh >> 16) ? inv_keep : 0.f;
+}
+// scales of elements idx..idx+3, idx % 4 == 0
+__device__ __forceinline__ void dropout_scale4(unsigned long long seed, unsigned long long idx, unsigned thresh,
+                                               float inv_keep, float* sc) {
+    const u32x2 b = dropout_bits4(seed, idx >> 2);
+    const unsigned t = thresh >> 16;
+    sc[0] = (b[0] & 0xffffu) >= t ? inv_keep : 0.f;
+    sc[1] = (b[0] >> 16) >= t ? inv_keep : 0.f;
+    sc[2] = (b[1] & 0xffffu) >= t ? inv_keep : 0.f;
+    sc[3] = (b[1] >> 16) >= t ? inv_keep : 0.f;
 }
 inline unsigned dropout_thresh(float p) {
     double t = (double)p * 4294967296.0;
@@ -185,6 +217,37 @@ __device__ __forceinline__ float gelu_erf(float x) {
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float kInvSqrt2Pi = 0.39894228040143267794f;
     return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
+}
+// Throughput-mode (bf16 activations) GELU: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16
+// resolution) = one v_rcp, one v_exp and six fma instead of libm's branchy erff; e = exp(-x^2/2) is shared with the
+// Gaussian term of the derivative.  The exact-f32 mode keeps erff.
+__device__ __forceinline__ float erf_as_from_exp(float ax, float e) {   // erf(ax / sqrt2) for ax >= 0, e = exp(-ax^2/2)
+    const float t = __frcp_rn(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    return fmaf(-p * t, e, 1.f);
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float ax = fabsf(x);
+    const float e = __expf(-0.5f * ax * ax);
+    const float er = copysignf(erf_as_from_exp(ax, e), x);
+    return 0.5f * x * (1.f + er);
+}
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    const float ax = fabsf(x);
+    const float e = __expf(-0.5f * ax * ax);
+    const float er = copysignf(erf_as_from_exp(ax, e), x);
+    return fmaf(x * 0.39894228040143267794f, e, 0.5f * (1.f + er));
+}
+template <typename T> __device__ __forceinline__ float gelu_fwd_t(float x) {
+    if constexpr (sizeof(T) == 2) return gelu_fast(x);
+    else return gelu_erf(x);
+}
+template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) {
+    if constexpr (sizeof(T) == 2) return gelu_grad_fast(x);
+    else return gelu_erf_grad(x);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

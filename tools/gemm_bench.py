@@ -22,8 +22,22 @@ lib.hs_prof_enable.argtypes = [C.c_int32]
 lib.hs_prof_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
 
 
+FLUSH = None
+
+
 def timeit(fn, iters=20):
-    """device-side duration of the main GEMM kernel (HIP events around each launch), seconds"""
+    """device-side duration of the main GEMM kernel (HIP events around each launch), seconds.
+    --cold: a 768 MB fill between launches evicts L2 and the Infinity Cache, like the neighbours of a GEMM inside a step."""
+    global FLUSH
+    cold = "--cold" in sys.argv
+    if cold and FLUSH is None:
+        FLUSH = torch.empty(768 << 20, dtype=torch.uint8, device=DEV)
+    if cold:
+        inner = fn
+
+        def fn():   # noqa: F811
+            FLUSH.add_(1)
+            inner()
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -47,6 +61,10 @@ def gemm_case(kind, M, N, K):
         A, B = torch.randn(K, M, device=DEV).to(BF), torch.randn(K, N, device=DEV).to(BF)
         kw = dict(a_kind=L.A_RC, b_kind=L.B_RC, lda=M, ldb=N)
     D = torch.empty(M, N, device=DEV, dtype=torch.float32 if kind == "tn" else BF)
+    if "--gelu" in sys.argv and kind != "tn":     # FFN1-style epilogue: bias + erf-GELU + pre-activation copy
+        bias = torch.randn(N, device=DEV)
+        pre = torch.empty_like(D)
+        kw.update(bias=bias, act=L.ACT_GELU, preact=pre)
     return lambda: raw.gemm(A, B, D, M, N, K, **kw)
 
 
