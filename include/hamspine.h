@@ -117,7 +117,7 @@ int32_t hs_gemm_suggest_split(int32_t M, int32_t N, int32_t K, int32_t dtype);
    Classes: 0 bf16 GEMM, 1 bf16 implicit-GEMM conv, 2 f32 GEMM, 3 f32 conv.  hs_prof_collect synchronises the
    device, fills 4 entries of algorithmic flops / elapsed ms / launch counts and clears the records. */
 /* measurement only: force a tile configuration (0 128x128, 1 128x64, 2 64x64, -1 auto) and ablation bits
-   (1 = skip global loads after the first K tile, 2 = skip the MFMAs). Results are wrong when ablate != 0. */
+   (16 = plain n-fastest tile order instead of the L2-grouped one; results stay correct). */
 void hs_gemm_debug(int32_t cfg_override, int32_t ablate);
 void hs_prof_enable(int32_t on);
 hs_status hs_prof_collect(double* flops, double* ms, int64_t* launches);

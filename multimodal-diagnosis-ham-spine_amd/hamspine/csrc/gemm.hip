@@ -3,6 +3,7 @@
 #include <unordered_set>
 #include <vector>
 #include <stdarg.h>
+#include <math.h>
 #include "gemm_launch.h"
 
 namespace hs {
@@ -213,6 +214,17 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     else if (cfg == CFG_128x64 || cfg == CFG_STEM || cfg == CFG_128x64x32) { BM = 128; BN = 64; }
     a.tiles_m = ceil_div(p->M, BM);
     a.tiles_n = ceil_div(p->N, BN);
+    {
+        // L2 grouping: an XCD runs S workgroups at a time (32 CUs x resident workgroups); the panels they touch are
+        // fewest when group_m * BM == (S / group_m) * BN
+        const int lds = 3 * (BM + BN) * (bf16 ? 64 * 2 : 32 * 4);
+        const int per_cu = std::max(1, std::min(4, (160 * 1024) / lds));
+        const double S = 32.0 * per_cu;
+        int gm = (int)(sqrt(S * BN / BM) + 0.5);
+        gm = std::max(1, std::min(gm, a.tiles_m));
+        if (g_dbg_ablate & 16) gm = 1;   // measurement: plain n-fastest order
+        a.group_m = gm;
+    }
 
     a.split_k = split;
     if (split > 1) {

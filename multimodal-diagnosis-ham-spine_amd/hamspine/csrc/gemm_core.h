@@ -32,6 +32,7 @@ struct GemmArgs {
     int batch_inner;
     long long a_bs0, a_bs1, b_bs0, b_bs1, d_bs0, d_bs1;   // in elements
     int tiles_m, tiles_n;
+    int group_m;               // tile rows per L2 group (tile_from_block)
     int split_k;               // >1: blockIdx.z is the split index
     int k_per_split;           // multiple of BK
     float* splitk_ws;
@@ -366,19 +367,22 @@ constexpr bool a_is_rc(int k) { return k == HS_A_RC; }
 constexpr bool b_is_rc(int k) { return k != HS_B_KC; }
 
 __device__ __forceinline__ void tile_from_block(const GemmArgs& a, int& tm, int& tn) {
-    // XCD-aware remap: the 8 XCDs get contiguous runs of tiles (bijective for any grid size), and
-    // inside a run tiles walk n fastest so neighbours share the A panel through the XCD's L2.
+    // XCD-aware remap: workgroup ids go round-robin over the 8 XCDs, so XCD x is handed the contiguous run of tile
+    // ids [x*nwg/8, (x+1)*nwg/8) (bijective for any grid size).  Tile ids walk the output in groups of `group_m` tile
+    // rows, m fastest inside a group: the workgroups an XCD runs at one time then cover group_m x (S/group_m) tiles
+    // and share group_m A panels and S/group_m B panels through that XCD's L2 (each XCD has its own L2; with plain
+    // n-fastest order one XCD streamed the whole B operand once per tile row).
     const int nwg = a.tiles_m * a.tiles_n;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    if (a.ablate & 16) {          // experiment: m fastest (the B panel of a few n tiles stays in the XCD's L2)
-        tn = id / a.tiles_m;
-        tm = id - tn * a.tiles_m;
-    } else {
-        tm = id / a.tiles_n;
-        tn = id - tm * a.tiles_n;
-    }
+    const int gsz = a.group_m * a.tiles_n;
+    const int grp = id / gsz;
+    const int first_m = grp * a.group_m;
+    const int gm = min(a.group_m, a.tiles_m - first_m);
+    const int within = id - grp * gsz;
+    tn = within / gm;
+    tm = first_m + (within - tn * gm);
 }
 
 // ================================================================================================
