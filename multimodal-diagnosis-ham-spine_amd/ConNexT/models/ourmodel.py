@@ -84,12 +84,17 @@ class OurClassfierConvnextV2(nn.Module):
         self.fc = Linear(768, num_labels)
 
     def forward(self, batch_data):
-        text = self.text_encoder(batch_data["input_ids"], batch_data["attention_mask"])      # (B, 768) f32
-        images = batch_data["transformed_image"]
-        if self._use_hf:
-            image = self.image_encoder(images).last_hidden_state
+        ids, mask, images = batch_data["input_ids"], batch_data["attention_mask"], batch_data["transformed_image"]
+
+        def image_tower():
+            return self.image_encoder(images).last_hidden_state if self._use_hf else self.image_encoder(images)
+        if rt.towers_overlap_enabled() and ids.is_cuda:      # BERT on a side stream beside the ConvNeXt
+            text, join = rt.run_on_tower_stream(lambda: self.text_encoder(ids, mask), ids, mask)   # (B, 768) f32
+            image = image_tower()
+            join(text)
         else:
-            image = self.image_encoder(images)
+            text = self.text_encoder(ids, mask)
+            image = image_tower()
         image_reduced = self.conv(image)                                                        # (B, 768, h, w)
         text_expanded = text.unsqueeze(-1).unsqueeze(-1)
         b = images.shape[0]

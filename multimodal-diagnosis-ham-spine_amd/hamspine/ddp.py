@@ -116,9 +116,11 @@ class DataParallel(nn.Module):
         if self.world == 1:
             return
         if self.on_gpu:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-            self.comm_stream.wait_event(ev)
+            # the bucket's gradients may come from either tower's stream: order the collective behind all of them
+            self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+            for s in rt.side_streams():
+                if s.device == self.device:
+                    self.comm_stream.wait_stream(s)
             with torch.cuda.stream(self.comm_stream):
                 b.work = dist.all_reduce(b.flat, op=self._avg_op, group=self.pg, async_op=True)
         else:

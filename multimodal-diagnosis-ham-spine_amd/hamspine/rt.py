@@ -17,10 +17,12 @@ def stream():
 
 
 def workspace(nbytes, device):
-    """One growing scratch buffer per (device, thread).  All kernels of one thread are ordered on the
-    current stream, so reuse between consecutive calls is safe; the autograd engine thread gets its
-    own buffer so a forward running ahead on the main thread never shares scratch with a backward."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), threading.get_ident())
+    """One growing scratch buffer per (device, thread, stream).  All kernels launched by one thread on one stream
+    are ordered, so reuse between consecutive calls is safe; the autograd engine thread gets its own buffer so a
+    forward running ahead on the main thread never shares scratch with a backward, and towers running concurrently
+    on different streams never share scratch either."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), threading.get_ident(),
+           torch.cuda.current_stream().cuda_stream)
     t = _ws.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
@@ -41,6 +43,53 @@ def reset_seed(base=None):
     with _seed_lock:
         _seed_state["base"] = base
         _seed_state["ctr"] = 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# tower-level concurrency: the text tower runs on a side HIP stream next to the image tower (they are independent
+# until the fusion operator), so the small ResNet kernels and the BERT GEMMs fill each other's gaps.  autograd runs
+# each tower's backward on the stream its forward used and orders the junctions itself.
+# ------------------------------------------------------------------------------------------------------------------
+_tower_streams = {}
+
+
+def towers_overlap_enabled():
+    import os
+    return os.environ.get("HAMSPINE_TOWER_OVERLAP", "1") != "0"
+
+
+def tower_stream(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    s = _tower_streams.get(idx)
+    if s is None:
+        s = torch.cuda.Stream(device=idx)
+        _tower_streams[idx] = s
+    return s
+
+
+def side_streams():
+    """streams hamspine may have work on besides the ambient one (collectives must order behind them too)"""
+    return list(_tower_streams.values())
+
+
+def run_on_tower_stream(fn, *inputs):
+    """fn() on the side stream, ordered after everything enqueued so far on the ambient stream.  Returns (result, join);
+    call join(*outputs) on the ambient stream before the first consumer of the outputs."""
+    cur = torch.cuda.current_stream()
+    side = tower_stream(cur.device)
+    side.wait_stream(cur)
+    for t in inputs:                       # inputs were allocated on the ambient stream: keep them alive for `side`
+        if torch.is_tensor(t):
+            t.record_stream(side)
+    with torch.cuda.stream(side):
+        out = fn()
+
+    def join(*outs):
+        cur.wait_stream(side)
+        for t in outs:                     # allocated on `side`, consumed on the ambient stream
+            if torch.is_tensor(t):
+                t.record_stream(cur)
+    return out, join
 
 
 _grad_arena = {}

@@ -4,6 +4,7 @@ import torch
 import torch.nn as nn
 
 from hamspine import functional as F
+from hamspine import rt
 from hamspine import small as S
 from hamspine.nn import Linear, resnet50
 
@@ -50,8 +51,14 @@ class Resnet50WithOurs(nn.Module):
         return _MLP(input_dim, num_labels)
 
     def forward(self, batch_data):
-        text = self.text_encoder(batch_data["input_ids"], batch_data["attention_mask"])   # (B, 768) f32
-        image = self.image_encoder(batch_data["transformed_image"])                      # (B, 768) f32
+        ids, mask = batch_data["input_ids"], batch_data["attention_mask"]
+        if rt.towers_overlap_enabled() and ids.is_cuda:      # BERT on a side stream beside the ResNet
+            text, join = rt.run_on_tower_stream(lambda: self.text_encoder(ids, mask), ids, mask)   # (B, 768) f32
+            image = self.image_encoder(batch_data["transformed_image"])                      # (B, 768) f32
+            join(text)
+        else:
+            text = self.text_encoder(ids, mask)
+            image = self.image_encoder(batch_data["transformed_image"])
         text_tok, image_tok = text.unsqueeze(1), image.unsqueeze(1)
         text_fused = self.textbased_cross_attention(image_tok, text_tok)    # query = image (reference naming quirk)
         imag_fused = self.imagbased_cross_attention(text_tok, image_tok)

@@ -6,6 +6,7 @@ import torch.nn as nn
 
 from encoder import ImageEncoder, TextEncoder
 from hamspine import functional as F
+from hamspine import rt
 from hamspine import small as S
 from hamspine.nn import Linear, MLPHead
 from modules.fusion_blocks import (
@@ -118,10 +119,17 @@ class MultimodalBaselineModel(nn.Module):
     # ------------------------------------------------------------------------------------------
     def forward_features(self, image_input, text_input_ids, text_attention_mask, tabular_input=None,
                          ablation_mode=None):
-        image_tokens, pooled_image = self._encode_image_tokens(image_input)
         if ablation_mode == "image_only":
-            return pooled_image
-        text_tokens = self.text_encoder(text_input_ids, text_attention_mask)
+            return self._encode_image_tokens(image_input)[1]
+        if rt.towers_overlap_enabled() and image_input.is_cuda:
+            # the towers are independent until the fusion operator: BERT on a side stream beside the ResNet
+            text_tokens, join = rt.run_on_tower_stream(
+                lambda: self.text_encoder(text_input_ids, text_attention_mask), text_input_ids, text_attention_mask)
+            image_tokens, pooled_image = self._encode_image_tokens(image_input)
+            join(text_tokens)
+        else:
+            image_tokens, pooled_image = self._encode_image_tokens(image_input)
+            text_tokens = self.text_encoder(text_input_ids, text_attention_mask)
         if ablation_mode == "text_off":
             text_tokens = F.axpby(text_tokens, None, 0.0, 0.0)   # zeros_like, keeps the graph shape
         if self.sequence_enabled and isinstance(self.fusion, MultiScaleFusionModule):

@@ -31,9 +31,23 @@ def main():
     opt = FusedAdamW(net.parameters(), lr=1e-4, weight_decay=0.01)
     images, ids, mask, labels = bench.synthetic(0, dev)
 
+    side = torch.cuda.Stream()
+    overlap = "--towers" in sys.argv
+
+    def features():
+        if not overlap:
+            return net.forward_features(images, ids, mask)
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            text_tokens = net.text_encoder(ids, mask)
+        image_tokens, _ = net._encode_image_tokens(images)
+        cur.wait_stream(side)
+        return net.fusion(image_tokens, text_tokens, mask)
+
     def step():
         opt.zero_grad(set_to_none=True)
-        logits = net.classifier(net.forward_features(images, ids, mask))
+        logits = net.classifier(features())
         loss = F.cross_entropy(logits, labels, label_smoothing=0.02)
         loss.backward()
         opt.step()
