@@ -10,6 +10,15 @@
 
 namespace hs {
 
+// dst = [a | b | c], n floats each (fused QKV bias)
+__global__ __launch_bounds__(256) void gather3_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      const float* __restrict__ c, float* __restrict__ dst, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 3 * n) return;
+    const int w = i / n, k = i - w * n;
+    dst[i] = w == 0 ? a[k] : (w == 1 ? b[k] : c[k]);
+}
+
 int gemm_impl(const hs_gemm_params* p, hipStream_t stream);
 
 static inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
@@ -822,9 +831,8 @@ static int bert_layer_fwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
                 HS_CHECK_HIP(hipMemcpyAsync((char*)L.wqkv + (long long)i * Hd * Hd * 4, ws3[i], (long long)Hd * Hd * 4,
                                             hipMemcpyDeviceToDevice, r.s));
         }
-        const float* bs3[3] = {d.q.b, d.k.b, d.v.b};
-        for (int i = 0; i < 3; ++i)
-            HS_CHECK_HIP(hipMemcpyAsync(L.bqkv + (long long)i * Hd, bs3[i], (long long)Hd * 4, hipMemcpyDeviceToDevice, r.s));
+        hipLaunchKernelGGL(gather3_kernel, dim3(ceil_div(3 * Hd, 256)), dim3(256), 0, r.s, d.q.b, d.k.b, d.v.b, L.bqkv, Hd);
+        HS_LAUNCH_CHECK();
     }
     // 1. fused QKV projection
     hs_linear qkv_lin;

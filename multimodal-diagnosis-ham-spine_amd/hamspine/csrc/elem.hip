@@ -326,6 +326,36 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     for (long long r = blockIdx.y; r < M; r += gridDim.y) acc += to_f32(x[r * ld + c]);
     ws[(long long)blockIdx.y * N + c] = acc;
 }
+// 16-byte variant (N, ld multiples of the chunk, base aligned): 64 chunk columns x 4 row lanes per block, the row
+// lanes merged through LDS in a fixed order
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const T* __restrict__ x, long long M, int N, int ld,
+                                                                 float* __restrict__ ws) {
+    constexpr int E = Chunk<T>::N;
+    __shared__ float sh[4][64 * E];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int cc = blockIdx.x * 64 + tx;
+    const bool live = cc * E < N;
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    if (live) {
+        for (long long r = (long long)blockIdx.y * 4 + ty; r < M; r += (long long)gridDim.y * 4) {
+            float f[E];
+            Chunk<T>::unpack(*(const u32x4*)(x + r * ld + (long long)cc * E), f);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] += f[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) sh[ty][tx * E + e] = acc[e];
+    __syncthreads();
+    if (ty == 0 && live) {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            ws[(long long)blockIdx.y * N + cc * E + e] = (sh[0][tx * E + e] + sh[1][tx * E + e]) + (sh[2][tx * E + e] + sh[3][tx * E + e]);
+    }
+}
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ ws, int gy, int N,
                                                            float* __restrict__ out, int accumulate) {
     __shared__ float sh[4][64];
@@ -684,12 +714,17 @@ static int mean_tokens_bwd_t(const void* dy, void* dx, int B, int Nt, int H, int
     return HS_OK;
 }
 
+static inline int colsum_gy(long long M) { return (int)std::min<long long>(std::max<long long>(M / 16, 1), 64); }
 template <typename T>
 static int colsum_t(const void* x, long long M, int N, int ld, float* out, float* ws, long long ws_bytes, int accumulate,
                     hipStream_t s) {
-    int gy = (int)std::min<long long>(std::max<long long>(M / 8, 1), 256);
+    constexpr int E = Chunk<T>::N;
+    const int gy = colsum_gy(M);
     HS_REQUIRE(ws && ws_bytes >= (long long)gy * N * 4, "colsum: workspace too small");
-    hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3(ceil_div(N, 256), gy), dim3(256), 0, s, (const T*)x, M, N, ld, ws);
+    if (N % E == 0 && ld % E == 0 && ((((uintptr_t)x) & 15) == 0))
+        hipLaunchKernelGGL(colsum_partial_vec_kernel<T>, dim3(ceil_div(N / E, 64), gy), dim3(256), 0, s, (const T*)x, M, N, ld, ws);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3(ceil_div(N, 256), gy), dim3(256), 0, s, (const T*)x, M, N, ld, ws);
     HS_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, s, ws, gy, N, out, accumulate);
     HS_LAUNCH_CHECK();
@@ -870,9 +905,7 @@ hs_status hs_colsum(int32_t dtype, const void* x, int64_t M, int32_t N, int32_t 
     HS_REQUIRE(x && out && M > 0 && N > 0, "colsum: bad argument");
     return DISPATCH_T(dtype, colsum_t, x, M, N, ld, out, (float*)ws, ws_bytes, accumulate, (hipStream_t)stream);
 }
-int64_t hs_colsum_ws_bytes(int64_t M, int32_t N) {
-    return std::min<long long>(std::max<long long>(M / 8, 1), 256) * N * 4;
-}
+int64_t hs_colsum_ws_bytes(int64_t M, int32_t N) { return (int64_t)colsum_gy(M) * N * 4; }
 hs_status hs_softmax_fwd(int32_t dtype, const float* S, const int64_t* mask, void* P, void* P_drop, int64_t rows,
                          int32_t Lk, int32_t ldS, int32_t ldP, int32_t rows_per_batch, float dropout_p, uint64_t seed,
                          void* stream) {

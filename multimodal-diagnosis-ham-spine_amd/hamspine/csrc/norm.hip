@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 }
 
 // backward: each wave walks rows (stride = total waves), writes dx and keeps per-lane dgamma/dbeta
-// partials which are written to ws[wave][2][H]; a second kernel reduces over waves.
+// partials; the block's four waves merge theirs through LDS into ws[block][2][H]; a second kernel reduces over blocks.
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -503,17 +503,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             }
         }
     }
+    // merge the four waves of the block in a fixed order through LDS, then one partial row per block
+    extern __shared__ float ln_sh[];   // [2][H]
+    const int wv = threadIdx.x >> 6;
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wv == turn) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nch) {
+            for (int i = 0; i < LN_MAXV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nch) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                ws[((long long)wid * 2 + 0) * H + c * E + e] = dg[i][e];
-                ws[((long long)wid * 2 + 1) * H + c * E + e] = db[i][e];
+                    for (int e = 0; e < E; ++e) {
+                        const int k = c * E + e;
+                        if (turn == 0) {
+                            ln_sh[k] = dg[i][e];
+                            ln_sh[H + k] = db[i][e];
+                        } else {
+                            ln_sh[k] += dg[i][e];
+                            ln_sh[H + k] += db[i][e];
+                        }
+                    }
+                }
             }
         }
+        __syncthreads();
     }
+    for (int k = threadIdx.x; k < 2 * H; k += 256) ws[(long long)blockIdx.x * 2 * H + k] = ln_sh[k];
 }
 __global__ __launch_bounds__(256) void ln_bwd_final_kernel(const float* __restrict__ ws, int nw, int H,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
@@ -548,7 +563,7 @@ __global__ __launch_bounds__(256) void ln_bwd_final_kernel(const float* __restri
 
 static int ln_bwd_blocks(long long M) {
     long long b = (M + 15) / 16;   // >= 4 rows per wave
-    if (b > 128) b = 128;
+    if (b > 512) b = 512;          // 2 workgroups per CU
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -570,11 +585,11 @@ static int ln_bwd_t(const void* dy, const void* x, const float* gamma, const flo
     constexpr int E = Chunk<T>::N;
     HS_REQUIRE(H % E == 0 && H <= 64 * E * LN_MAXV, "layernorm_bwd: H=%d unsupported for this dtype", H);
     const int blocks = ln_bwd_blocks(M);
-    HS_REQUIRE(ws && ws_bytes >= (long long)blocks * 4 * 2 * H * 4, "layernorm_bwd: workspace too small");
-    hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3(blocks), dim3(256), 0, s, (const T*)dy, (const T*)x, gamma, mean, rstd,
-                       (T*)dx, ws, M, H);
+    HS_REQUIRE(ws && ws_bytes >= (long long)blocks * 2 * H * 4, "layernorm_bwd: workspace too small");
+    hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3(blocks), dim3(256), 2 * H * sizeof(float), s, (const T*)dy, (const T*)x, gamma,
+                       mean, rstd, (T*)dx, ws, M, H);
     HS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3(ceil_div(H, 64)), dim3(256), 0, s, ws, blocks * 4, H, dgamma, dbeta);
+    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3(ceil_div(H, 64)), dim3(256), 0, s, ws, blocks, H, dgamma, dbeta);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
@@ -591,7 +606,7 @@ int ln_bwd(int dtype, const void* dy, const void* x, const float* gamma, const f
     return dtype == HS_BF16 ? ln_bwd_t<bf16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, ws_bytes, M, H, s)
                             : ln_bwd_t<float>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, ws_bytes, M, H, s);
 }
-long long ln_bwd_ws_bytes(long long M, int H) { return (long long)ln_bwd_blocks(M) * 4 * 2 * H * 4; }
+long long ln_bwd_ws_bytes(long long M, int H) { return (long long)ln_bwd_blocks(M) * 2 * H * 4; }
 
 }  // namespace hs
 
