@@ -463,6 +463,120 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
     }
 }
 
+// 16-byte variants for Lk % 4 == 0, Lk <= 256 and 4-aligned pitches: G = pow2 >= Lk/4 lanes own one row (4 consecutive
+// keys per lane), so a wave carries 64/G rows, every access is a 16/8-byte vector and one dropout hash serves 4 elements.
+template <int G> __device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <typename T> __device__ __forceinline__ void store4_any(T* p, const float* f);
+template <> __device__ __forceinline__ void store4_any<float>(float* p, const float* f) {
+    *(f32x4*)p = f32x4{f[0], f[1], f[2], f[3]};
+}
+template <> __device__ __forceinline__ void store4_any<bf16_t>(bf16_t* p, const float* f) {
+    *(bf16x4*)p = bf16x4{(bf16_t)f[0], (bf16_t)f[1], (bf16_t)f[2], (bf16_t)f[3]};
+}
+template <typename T> __device__ __forceinline__ void load4_any(const T* p, float* f);
+template <> __device__ __forceinline__ void load4_any<float>(const float* p, float* f) {
+    const f32x4 v = *(const f32x4*)p;
+    f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+}
+template <> __device__ __forceinline__ void load4_any<bf16_t>(const bf16_t* p, float* f) {
+    const u32x2 v = *(const u32x2*)p;
+    f[0] = __uint_as_float(v[0] << 16); f[1] = __uint_as_float(v[0] & 0xffff0000u);
+    f[2] = __uint_as_float(v[1] << 16); f[3] = __uint_as_float(v[1] & 0xffff0000u);
+}
+
+template <typename T, int G>
+__global__ __launch_bounds__(256) void softmax_fwd_vec_kernel(const float* __restrict__ S, const long long* __restrict__ mask,
+                                                              T* __restrict__ P, T* __restrict__ Pd, long long rows, int Lk,
+                                                              int ldS, int ldP, int rows_per_batch, unsigned thresh,
+                                                              float inv_keep, unsigned long long seed) {
+    constexpr int RW = 64 / G;
+    const int lane = threadIdx.x & 63, sub = lane / G, li = lane % G;
+    const long long r = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW + sub;
+    if (r >= rows) return;            // whole row groups leave together; the shuffles below stay inside a group
+    const int k0 = li * 4;
+    const bool act = k0 < Lk;
+    float v[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (act) {
+        load4_any<float>(S + r * ldS + k0, v);
+        if (mask) {
+            const long long* mk = mask + (r / rows_per_batch) * Lk + k0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (mk[j] == 0) v[j] = -3.0e38f;
+        }
+    }
+    const float mx = group_max<G>(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+    float sum = 0.f;
+    if (act) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = __expf(v[j] - mx);
+            sum += v[j];
+        }
+    }
+    const float inv = 1.f / group_sum<G>(sum);
+    if (k0 < ldP) {
+        float p[4] = {0.f, 0.f, 0.f, 0.f};   // padding columns are written as zeros
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[j] = v[j] * inv;
+        }
+        store4_any<T>(P + r * ldP + k0, p);
+        if (Pd) {
+            if (thresh && act) {
+                float sc[4];
+                dropout_scale4(seed, (unsigned long long)r * Lk + k0, thresh, inv_keep, sc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p[j] *= sc[j];
+            }
+            store4_any<T>(Pd + r * ldP + k0, p);
+        }
+    }
+}
+template <typename T, int G>
+__global__ __launch_bounds__(256) void softmax_bwd_vec_kernel(const float* __restrict__ dP, const T* __restrict__ P,
+                                                              T* __restrict__ dS, long long rows, int Lk, int ldG, int ldP,
+                                                              unsigned thresh, float inv_keep, unsigned long long seed) {
+    constexpr int RW = 64 / G;
+    const int lane = threadIdx.x & 63, sub = lane / G, li = lane % G;
+    const long long r = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW + sub;
+    if (r >= rows) return;
+    const int k0 = li * 4;
+    const bool act = k0 < Lk;
+    float g[4] = {0.f, 0.f, 0.f, 0.f}, p[4] = {0.f, 0.f, 0.f, 0.f};
+    float dot = 0.f;
+    if (act) {
+        load4_any<float>(dP + r * ldG + k0, g);
+        load4_any<T>(P + r * ldP + k0, p);
+        if (thresh) {
+            float sc[4];
+            dropout_scale4(seed, (unsigned long long)r * Lk + k0, thresh, inv_keep, sc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] *= sc[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dot += g[j] * p[j];
+    }
+    dot = group_sum<G>(dot);
+    if (k0 < ldP) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = p[j] * (g[j] - dot);
+        }
+        store4_any<T>(dS + r * ldP + k0, o);
+    }
+}
+
 // ============================================================================================
 // BERT embeddings: word[ids] + pos[l] + type[0]  (pre-LN sum saved), LayerNorm, dropout.
 // Replaces transformers BertEmbeddings.forward under reference encoder.py:131 / mibf_net/bert.py:12.
@@ -731,13 +845,28 @@ static int colsum_t(const void* x, long long M, int N, int ld, float* out, float
     return HS_OK;
 }
 
+static inline int softmax_group(int Lk, int ldP) {   // lanes per row of the 16-byte kernels, 0 = not eligible
+    if (Lk % 4 || ldP % 4 || ldP > 256) return 0;
+    const int need = ldP / 4;
+    return need <= 16 ? 16 : (need <= 32 ? 32 : 64);
+}
 template <typename T>
 static int softmax_fwd_t(const float* S, const long long* mask, void* P, void* Pd, long long rows, int Lk, int ldS,
                          int ldP, int rpb, float p, unsigned long long seed, hipStream_t s) {
     HS_REQUIRE(Lk <= 64 * SM_MAXV && ldP <= 64 * SM_MAXV, "softmax: Lk=%d too long (max %d)", Lk, 64 * SM_MAXV);
     const unsigned th = p > 0.f ? dropout_thresh(p) : 0u;
-    hipLaunchKernelGGL(softmax_fwd_kernel<T>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, mask, (T*)P, (T*)Pd, rows, Lk,
-                       ldS, ldP, rpb, th, p > 0.f ? 1.f / (1.f - p) : 1.f, seed);
+    const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const int G = (ldS % 4 == 0 && ((((uintptr_t)S) | ((uintptr_t)P) | ((uintptr_t)Pd)) & 15) == 0) ? softmax_group(Lk, ldP) : 0;
+#define SM_FWD(GG)                                                                                                       \
+    hipLaunchKernelGGL((softmax_fwd_vec_kernel<T, GG>), dim3(ceil_div(rows, 4 * (64 / GG))), dim3(256), 0, s, S, mask, (T*)P, \
+                       (T*)Pd, rows, Lk, ldS, ldP, rpb, th, ik, seed)
+    if (G == 16) SM_FWD(16);
+    else if (G == 32) SM_FWD(32);
+    else if (G == 64) SM_FWD(64);
+    else
+        hipLaunchKernelGGL(softmax_fwd_kernel<T>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, mask, (T*)P, (T*)Pd, rows, Lk,
+                           ldS, ldP, rpb, th, ik, seed);
+#undef SM_FWD
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
@@ -746,8 +875,18 @@ static int softmax_bwd_t(const float* dP, const void* P, void* dS, long long row
                          unsigned long long seed, hipStream_t s) {
     HS_REQUIRE(Lk <= 64 * SM_MAXV && ldP <= 64 * SM_MAXV, "softmax_bwd: Lk=%d too long", Lk);
     const unsigned th = p > 0.f ? dropout_thresh(p) : 0u;
-    hipLaunchKernelGGL(softmax_bwd_kernel<T>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, dP, (const T*)P, (T*)dS, rows, Lk,
-                       ldG, ldP, th, p > 0.f ? 1.f / (1.f - p) : 1.f, seed);
+    const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const int G = (ldG % 4 == 0 && ((((uintptr_t)dP) | ((uintptr_t)P) | ((uintptr_t)dS)) & 15) == 0) ? softmax_group(Lk, ldP) : 0;
+#define SM_BWD(GG)                                                                                                      \
+    hipLaunchKernelGGL((softmax_bwd_vec_kernel<T, GG>), dim3(ceil_div(rows, 4 * (64 / GG))), dim3(256), 0, s, dP, (const T*)P, \
+                       (T*)dS, rows, Lk, ldG, ldP, th, ik, seed)
+    if (G == 16) SM_BWD(16);
+    else if (G == 32) SM_BWD(32);
+    else if (G == 64) SM_BWD(64);
+    else
+        hipLaunchKernelGGL(softmax_bwd_kernel<T>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, dP, (const T*)P, (T*)dS, rows, Lk,
+                           ldG, ldP, th, ik, seed);
+#undef SM_BWD
     HS_LAUNCH_CHECK();
     return HS_OK;
 }

@@ -214,10 +214,16 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     else if (cfg == CFG_128x64 || cfg == CFG_STEM || cfg == CFG_128x64x32) { BM = 128; BN = 64; }
     a.tiles_m = ceil_div(p->M, BM);
     a.tiles_n = ceil_div(p->N, BN);
+    const int kb_cfg = (cfg == CFG_STEM || cfg == CFG_128x128x32 || cfg == CFG_128x64x32) ? 32 : bk;
     {
+        // K tiles one workgroup walks -> LDS ring slots it needs (a single-tile 1x1 convolution allocates one slot, so
+        // 5-6 workgroups instead of 2 share a CU and hide each other's load -> MFMA -> store latency chain)
+        const int ktiles_all = ceil_div(p->K, kb_cfg);
+        const int kt = split > 1 ? ceil_div(ktiles_all, split) : ktiles_all;
+        a.lds_stages = std::max(1, std::min(3, kt));
         // L2 grouping: an XCD runs S workgroups at a time (32 CUs x resident workgroups); the panels they touch are
         // fewest when group_m * BM == (S / group_m) * BN
-        const int lds = 3 * (BM + BN) * (bf16 ? 64 * 2 : 32 * 4);
+        const int lds = bf16 ? a.lds_stages * (BM + BN) * kb_cfg * 2 : 2 * (BM + BN) * 32 * 4;
         const int per_cu = std::max(1, std::min(4, (160 * 1024) / lds));
         const double S = 32.0 * per_cu;
         int gm = (int)(sqrt(S * BN / BM) + 0.5);
@@ -229,9 +235,8 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     a.split_k = split;
     if (split > 1) {
         HS_REQUIRE(p->splitk_ws != nullptr, "hs_gemm: split_k needs a workspace");
-        const int kb = (cfg == CFG_STEM || cfg == CFG_128x128x32 || cfg == CFG_128x64x32) ? 32 : bk;
-        const int ktiles = ceil_div(p->K, kb);
-        a.k_per_split = ceil_div(ktiles, split) * kb;
+        const int ktiles = ceil_div(p->K, kb_cfg);
+        a.k_per_split = ceil_div(ktiles, split) * kb_cfg;
         a.splitk_ws = p->splitk_ws;
     }
     dim3 grid(a.tiles_m * a.tiles_n, 1, split > 1 ? split : batch);

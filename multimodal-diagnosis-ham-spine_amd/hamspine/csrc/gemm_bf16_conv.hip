@@ -1,7 +1,7 @@
 #include "gemm_launch.h"
 namespace hs {
 #define L(BM, BN, BK, AK, BKD) \
-    return launch_with_lds(gemm_bf16_kernel<BM, BN, BK, AK, BKD, true>, 3 * (BM + BN) * BK * 2, a, grid, s)
+    return launch_with_lds(gemm_bf16_kernel<BM, BN, BK, AK, BKD, true>, a.lds_stages * (BM + BN) * BK * 2, 3 * (BM + BN) * BK * 2, a, grid, s)
 #define CFGS(AK, BKD)                              \
     switch (cfg) {                                 \
         case CFG_128x128: L(128, 128, 64, AK, BKD); \

@@ -33,6 +33,7 @@ struct GemmArgs {
     long long a_bs0, a_bs1, b_bs0, b_bs1, d_bs0, d_bs1;   // in elements
     int tiles_m, tiles_n;
     int group_m;               // tile rows per L2 group (tile_from_block)
+    int lds_stages;            // ring slots actually allocated: min(3, K tiles per workgroup) (bf16 kernel)
     int split_k;               // >1: blockIdx.z is the split index
     int k_per_split;           // multiple of BK
     float* splitk_ws;

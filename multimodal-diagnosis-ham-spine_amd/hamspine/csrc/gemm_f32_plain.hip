@@ -1,7 +1,7 @@
 #include "gemm_launch.h"
 namespace hs {
 #define L(BM, BN, AK, BKD, V) \
-    return launch_with_lds(gemm_f32_kernel<BM, BN, AK, BKD, V>, 2 * (BM + BN) * 32 * 4, a, grid, s)
+    return launch_with_lds(gemm_f32_kernel<BM, BN, AK, BKD, V>, 2 * (BM + BN) * 32 * 4, 2 * (BM + BN) * 32 * 4, a, grid, s)
 #define CFGS(AK, BKD)                                             \
     if (!vec) L(64, 64, AK, BKD, false);                          \
     switch (cfg) {                                                \

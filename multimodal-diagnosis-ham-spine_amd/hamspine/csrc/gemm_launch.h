@@ -11,10 +11,11 @@ int launch_f32_conv(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_
 
 bool lds_attr_needed(const void* fn);   // true the first time a kernel pointer is seen (thread safe)
 
+// lds: dynamic LDS of this launch; max_lds: the most this kernel is ever launched with (set once as its limit)
 template <typename K>
-inline int launch_with_lds(K kernel, int lds, const GemmArgs& a, dim3 grid, hipStream_t s) {
-    if (lds >= 48 * 1024 && lds_attr_needed((const void*)kernel)) {
-        HS_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+inline int launch_with_lds(K kernel, int lds, int max_lds, const GemmArgs& a, dim3 grid, hipStream_t s) {
+    if (max_lds >= 48 * 1024 && lds_attr_needed((const void*)kernel)) {
+        HS_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     }
     hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, a);
     HS_LAUNCH_CHECK();
