@@ -754,16 +754,34 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable t, floa
     float* m = t.m[e];
     float* v = t.v[e];
     const long long n = t.n[e];
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        float pi = p[i], gi = g[i] * grad_scale;
+    auto upd = [&](float& pi, float gi, float& mi, float& vi) {
+        gi *= grad_scale;
         if (decoupled) pi *= 1.f - lr * wd;
         else gi += wd * pi;
-        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
+        mi = beta1 * mi + (1.f - beta1) * gi;
+        vi = beta2 * vi + (1.f - beta2) * gi * gi;
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = pi - (lr / bc1) * (mi / denom);
+        pi = pi - (lr / bc1) * (mi / denom);
+    };
+    const bool al = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+    const long long n4 = al ? n / 4 : 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f32x4 pv = ((f32x4*)p)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+        const f32x4 gv = ((const f32x4*)g)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float pi = pv[k], mi = mv[k], vi = vv[k];
+            upd(pi, gv[k], mi, vi);
+            pv[k] = pi; mv[k] = mi; vv[k] = vi;
+        }
+        ((f32x4*)p)[i] = pv;
+        ((f32x4*)m)[i] = mv;
+        ((f32x4*)v)[i] = vv;
+    }
+    for (long long i = n4 * 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float pi = p[i], mi = m[i], vi = v[i];
+        upd(pi, g[i], mi, vi);
+        p[i] = pi; m[i] = mi; v[i] = vi;
     }
 }
 
@@ -1127,7 +1145,7 @@ hs_status hs_adam_step_multi(int32_t count, float* const* params, const float* c
             t.n[i] = n[base + i];
             mx = std::max<long long>(mx, t.n[i]);
         }
-        const int gx = (int)std::min<long long>(std::max<long long>((mx + 1023) / 1024, 1), 512);
+        const int gx = (int)std::min<long long>(std::max<long long>((mx + 4095) / 4096, 1), 256);
         hipLaunchKernelGGL(adam_multi_kernel, dim3(gx, cnt), dim3(256), 0, (hipStream_t)stream, t, lr, beta1, beta2, eps,
                            weight_decay, bc1, bc2s, decoupled, grad_scale);
         HS_LAUNCH_CHECK();

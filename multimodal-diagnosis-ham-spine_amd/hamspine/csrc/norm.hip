@@ -37,66 +37,115 @@ static ColGeom col_geom(long long M, int C, int epc) {
 // ============================================================================================
 // BatchNorm
 // ============================================================================================
-// stage 1: per (row block, channel) Welford partials (count, mean, M2)
+// block-level column reduction of per-thread partial sums: lanes of a wave that share a column (tx) first fold with
+// xor-shuffles (offsets tpc..32), then the four waves fold through LDS; fixed order -> deterministic.  Returns the
+// block total in the threads with ty == 0 (valid for every e).
+template <int E, int NV>
+__device__ __forceinline__ void block_col_reduce(float (&v)[NV][E], int tpc, float* sh /* [4][64*E*NV] or [256*E*NV] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (tpc < 64) {
+        for (int o = 32; o >= tpc; o >>= 1) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[k][e] += __shfl_xor(v[k][e], o, 64);
+        }
+        // lanes 0..tpc-1 of every wave now hold their wave's column sums
+        if (lane < tpc) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+#pragma unroll
+                for (int e = 0; e < E; ++e) sh[((wave * NV + k) * 64 + lane) * E + e] = v[k][e];
+        }
+        __syncthreads();
+        if (wave == 0 && lane < tpc) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    v[k][e] = (sh[((0 * NV + k) * 64 + lane) * E + e] + sh[((1 * NV + k) * 64 + lane) * E + e]) +
+                              (sh[((2 * NV + k) * 64 + lane) * E + e] + sh[((3 * NV + k) * 64 + lane) * E + e]);
+        }
+    } else {
+        // tpc in {64, 128, 256}: rows_par = 256 / tpc row lanes, one per (group of) wave(s)
+        const int rows_par = 256 / tpc, tx = threadIdx.x % tpc, ty = threadIdx.x / tpc;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int e = 0; e < E; ++e) sh[((ty * NV + k) * tpc + tx) * E + e] = v[k][e];
+        __syncthreads();
+        if (ty == 0) {
+            for (int j = 1; j < rows_par; ++j)
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) v[k][e] += sh[((j * NV + k) * tpc + tx) * E + e];
+        }
+    }
+}
+
+// stage 1: per (row block, channel) partials (count, mean, M2).  Sums are taken relative to a per-block, per-channel
+// shift x0 (the block's first row), which keeps sum((x-x0)^2) - sum(x-x0)^2/n well conditioned without Welford's
+// per-element division; four independent rows are in flight per thread.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const T* __restrict__ x, long long M, int C, int tpc,
                                                                float* __restrict__ ws) {
     constexpr int E = Chunk<T>::N;
+    __shared__ float sh[256 * E * 2];
     const int cg = C / E;
     const int tx = threadIdx.x % tpc, ty = threadIdx.x / tpc, rows_par = 256 / tpc;
     const int cc = blockIdx.x * tpc + tx;
-    float mean[E], m2[E];
+    const bool live = cc < cg;
+    const long long r0 = (long long)blockIdx.y * rows_par;
+    float x0[E], acc[2][E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) mean[e] = m2[e] = 0.f;
+    for (int e = 0; e < E; ++e) x0[e] = acc[0][e] = acc[1][e] = 0.f;
     float cnt = 0.f;
-    if (cc < cg) {
-        for (long long r = (long long)blockIdx.y * rows_par + ty; r < M; r += (long long)gridDim.y * rows_par) {
-            const u32x4 c = *(const u32x4*)(x + r * C + (long long)cc * E);
-            float f[E];
-            Chunk<T>::unpack(c, f);
-            cnt += 1.f;
-            const float inv = 1.f / cnt;
+    if (live) {
+        Chunk<T>::unpack(*(const u32x4*)(x + r0 * C + (long long)cc * E), x0);   // r0 < M by construction of the grid
+        const long long step = (long long)gridDim.y * rows_par;
+        long long r = r0 + ty;
+        const T* px = x + (long long)cc * E;
+        for (; r + 3 * step < M; r += 4 * step) {
+            float f[4][E];
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const float d = f[e] - mean[e];
-                mean[e] += d * inv;
-                m2[e] += d * (f[e] - mean[e]);
-            }
-        }
-    }
-    // merge across ty through LDS (fixed order -> deterministic)
-    __shared__ float s_cnt[256];
-    __shared__ float s_mean[256 * E];
-    __shared__ float s_m2[256 * E];
-    s_cnt[threadIdx.x] = cnt;
+            for (int u = 0; u < 4; ++u) Chunk<T>::unpack(*(const u32x4*)(px + (r + u * step) * C), f[u]);
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        s_mean[threadIdx.x * E + e] = mean[e];
-        s_m2[threadIdx.x * E + e] = m2[e];
-    }
-    __syncthreads();
-    if (ty == 0 && cc < cg) {
-        for (int j = 1; j < rows_par; ++j) {
-            const int o = j * tpc + tx;
-            const float nb = s_cnt[o];
-            if (nb > 0.f) {
-                const float n = cnt + nb;
-                const float w = nb / n;
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    const float d = s_mean[o * E + e] - mean[e];
-                    mean[e] += d * w;
-                    m2[e] += s_m2[o * E + e] + d * d * cnt * w;
+                    const float d = f[u][e] - x0[e];
+                    acc[0][e] += d;
+                    acc[1][e] = fmaf(d, d, acc[1][e]);
                 }
-                cnt = n;
-            }
+            cnt += 4.f;
         }
+        for (; r < M; r += step) {
+            float f[E];
+            Chunk<T>::unpack(*(const u32x4*)(px + r * C), f);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float d = f[e] - x0[e];
+                acc[0][e] += d;
+                acc[1][e] = fmaf(d, d, acc[1][e]);
+            }
+            cnt += 1.f;
+        }
+    }
+    // row count of the block: every column has the same one
+    float cv[1][1] = {{cnt}};
+    block_col_reduce<1, 1>(cv, tpc, sh);
+    __syncthreads();
+    block_col_reduce<E, 2>(acc, tpc, sh);
+    if (ty == 0 && live) {
+        const float n = cv[0][0];
         float* o = ws + ((long long)blockIdx.y * C + (long long)cc * E) * 3;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            o[e * 3 + 0] = cnt;
-            o[e * 3 + 1] = mean[e];
-            o[e * 3 + 2] = m2[e];
+            const float s1 = acc[0][e];
+            o[e * 3 + 0] = n;
+            o[e * 3 + 1] = x0[e] + s1 / n;
+            o[e * 3 + 2] = fmaxf(acc[1][e] - s1 * s1 / n, 0.f);
         }
     }
 }
@@ -207,51 +256,52 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
     const int cg = C / E;
     const int tx = threadIdx.x % tpc, ty = threadIdx.x / tpc, rows_par = 256 / tpc;
     const int cc = blockIdx.x * tpc + tx;
-    float s1[E], s2[E], mu[E], is[E];
+    float acc[2][E], mu[E], is[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) s1[e] = s2[e] = mu[e] = is[e] = 0.f;
+    for (int e = 0; e < E; ++e) acc[0][e] = acc[1][e] = mu[e] = is[e] = 0.f;
     if (cc < cg) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             mu[e] = mean[cc * E + e];
             is[e] = invstd[cc * E + e];
         }
-        for (long long r = (long long)blockIdx.y * rows_par + ty; r < M; r += (long long)gridDim.y * rows_par) {
-            const long long o = r * C + (long long)cc * E;
-            float g[E], xv[E], yv[E];
+        const long long step = (long long)gridDim.y * rows_par;
+        long long r = (long long)blockIdx.y * rows_par + ty;
+        auto row = [&](long long rr, float (&g)[E], float (&xv)[E], float (&yv)[E]) {
+            const long long o = rr * C + (long long)cc * E;
             Chunk<T>::unpack(*(const u32x4*)(dy + o), g);
             Chunk<T>::unpack(*(const u32x4*)(x + o), xv);
             if (relu) Chunk<T>::unpack(*(const u32x4*)(y + o), yv);
+        };
+        auto fold = [&](const float (&g)[E], const float (&xv)[E], const float (&yv)[E]) {
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const float dz = (relu && !(yv[e] > 0.f)) ? 0.f : g[e];
-                s1[e] += dz;
-                s2[e] += dz * (xv[e] - mu[e]) * is[e];
+                acc[0][e] += dz;
+                acc[1][e] = fmaf(dz, (xv[e] - mu[e]) * is[e], acc[1][e]);
             }
+        };
+        for (; r + step < M; r += 2 * step) {
+            float g0[E], x0[E], y0[E], g1[E], x1[E], y1[E];
+            row(r, g0, x0, y0);
+            row(r + step, g1, x1, y1);
+            fold(g0, x0, y0);
+            fold(g1, x1, y1);
+        }
+        for (; r < M; r += step) {
+            float g0[E], x0[E], y0[E];
+            row(r, g0, x0, y0);
+            fold(g0, x0, y0);
         }
     }
-    __shared__ float sh1[256 * E];
-    __shared__ float sh2[256 * E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        sh1[threadIdx.x * E + e] = s1[e];
-        sh2[threadIdx.x * E + e] = s2[e];
-    }
-    __syncthreads();
+    __shared__ float sh[256 * E * 2];
+    block_col_reduce<E, 2>(acc, tpc, sh);
     if (ty == 0 && cc < cg) {
-        for (int j = 1; j < rows_par; ++j) {
-            const int o = j * tpc + tx;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                s1[e] += sh1[o * E + e];
-                s2[e] += sh2[o * E + e];
-            }
-        }
         float* o = ws + ((long long)blockIdx.y * C + (long long)cc * E) * 2;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            o[e * 2 + 0] = s1[e];
-            o[e * 2 + 1] = s2[e];
+            o[e * 2 + 0] = acc[0][e];
+            o[e * 2 + 1] = acc[1][e];
         }
     }
 }
