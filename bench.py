@@ -127,6 +127,12 @@ def gpu_leg(args, rank, world, local_rank):
     lib.hs_prof_enable.argtypes = [C.c_int32]
     lib.hs_prof_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     fl, ms, cnt = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_int64 * 4)()
+    # one kernel at a time for this leg (no weight-gradient side stream, towers back to back): the events then bracket
+    # the kernel alone, which is what a per-kernel roofline means; the timed region above ran with both overlaps on
+    lib.hs_set_overlap(0)
+    os.environ["HAMSPINE_TOWER_OVERLAP"] = "0"
+    step()
+    fence()
     lib.hs_prof_enable(1)
     prof_steps = 2
     for _ in range(prof_steps):
@@ -138,14 +144,25 @@ def gpu_leg(args, rank, world, local_rank):
     fam_ms = ms[0] + ms[1]
     fam_launches = cnt[0] + cnt[1]
     achieved = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
+    # HBM traffic per launch of the same kernel family: PMC counters need their own rocprofv3 passes (FETCH_SIZE and
+    # WRITE_SIZE cannot share one on gfx950), so the figure is read from the committed summary of those passes
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic = round(tj["traffic_bytes_per_launch"])
+        traffic_src = "profiles/round1_pmc_traffic.json: " + tj["method"]
     roofline = {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+        "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
         "kernel": "gemm_bf16_kernel<BM,BN,BK,A,B> (bf16 MFMA GEMM + implicit-GEMM conv core)",
         "launches_per_step": fam_launches // prof_steps,
         "avg_launch_us": round(fam_ms * 1e3 / max(fam_launches, 1), 2),
         "kernel_ms_per_step": round(fam_ms / prof_steps, 3),
         "algorithmic_tflop_per_step": round(fam_flops / prof_steps / 1e12, 3),
+        "traffic_unit": "bytes per launch (PMC, separate passes)", "traffic_source": traffic_src,
+        "timing": "HIP events around every launch of the family on its own stream, 2 steps run without stream overlap",
         "split": {"gemm": {"tflops": round(fl[0] / max(ms[0], 1e-9) / 1e9, 1), "ms_per_step": round(ms[0] / prof_steps, 3)},
                   "conv": {"tflops": round(fl[1] / max(ms[1], 1e-9) / 1e9, 1), "ms_per_step": round(ms[1] / prof_steps, 3)}},
     }
@@ -154,6 +171,8 @@ def gpu_leg(args, rank, world, local_rank):
         step()
         L.check(lib.hs_prof_dump(args.gemm_log.encode()), "hs_prof_dump")
         lib.hs_prof_enable(0)
+    lib.hs_set_overlap(1)
+    os.environ["HAMSPINE_TOWER_OVERLAP"] = "1"
     return dt, final_loss, roofline, nparams
 
 
@@ -206,9 +225,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal hooks (not used by the driver): several ranks on one card over gloo exercise the N>1 code path on a
+    # one-GPU box -- HAMSPINE_DIST_BACKEND=gloo HAMSPINE_BENCH_DEVICE=0
+    backend = os.environ.get("HAMSPINE_DIST_BACKEND", "nccl")
+    if "HAMSPINE_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["HAMSPINE_BENCH_DEVICE"])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
     dt, final_loss, roofline, nparams = gpu_leg(args, rank, world, local_rank)
     if rank == 0:
         value = BATCH * world * args.steps / dt

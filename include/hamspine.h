@@ -388,6 +388,10 @@ hs_status hs_attention_bwd(const hs_attn_desc* d, const void* q, const void* k, 
                            void* dk, void* dv, void* saved, int64_t saved_bytes, void* ws, int64_t ws_bytes,
                            void* stream);
 
+/* weight-gradient side stream inside the composites below: 1 on (default; env HAMSPINE_OVERLAP=0 turns it off),
+   0 off = every kernel of a composite runs on the caller's stream (used to time kernels in isolation). */
+void hs_set_overlap(int32_t on);
+
 /* conv + BatchNorm pair of a residual block. `w` is the f32 filter stored KRSC (channels_last). */
 typedef struct hs_conv_bn {
     int32_t Cin, Cout, R, stride, pad;

@@ -58,13 +58,13 @@ static hipStream_t g_side_stream[16] = {};
 static hipEvent_t g_events[16][64] = {};
 static int g_event_next[16] = {};
 static std::mutex g_side_mu;
+static int g_overlap = -1;   // -1: take HAMSPINE_OVERLAP from the environment on first use
 static bool overlap_enabled() {
-    static int v = -1;
-    if (v < 0) {
+    if (g_overlap < 0) {
         const char* e = getenv("HAMSPINE_OVERLAP");
-        v = (e && e[0] == '0') ? 0 : 1;
+        g_overlap = (e && e[0] == '0') ? 0 : 1;
     }
-    return v == 1;
+    return g_overlap == 1;
 }
 static int side_setup(Run& r) {
     if (r.plan || !overlap_enabled()) return HS_OK;
@@ -1135,4 +1135,7 @@ int64_t hs_linear_bwd_ws_bytes(int64_t M, int32_t in_f, int32_t out_f, int32_t d
     const long long b = align_up(hs_colsum_ws_bytes(M, out_f), 256);
     return a + b + 1024;   // slabs and column-sum partials may be live together (side-stream overlap)
 }
+/* weight-gradient side stream inside the composites: 1 on (default, or HAMSPINE_OVERLAP), 0 off (every kernel of a
+   composite on the caller's stream, e.g. to time kernels in isolation). */
+void hs_set_overlap(int32_t on) { hs::g_overlap = on ? 1 : 0; }
 }

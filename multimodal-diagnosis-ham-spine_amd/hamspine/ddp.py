@@ -18,6 +18,8 @@ MI355X-first design
   * one wait on the side stream before optimizer.step() (`finish()`, also run automatically at the end of
     each backward through an autograd-engine callback).
 """
+import warnings
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -73,9 +75,13 @@ class DataParallel(nn.Module):
                 rt.grad_arena_register(p, b.views[i])
                 p.register_post_accumulate_grad_hook(self._on_grad)
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        # the text tower's gradients are produced on its own stream while the hooked AccumulateGrad nodes were created on
+        # the ambient one; autograd orders the two correctly and says so on every backward
+        warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")
         self._callback_queued = False
         self._dirty = False
-        self._avg_op = dist.ReduceOp.AVG if (self.on_gpu and self.world > 1) else dist.ReduceOp.SUM
+        nccl = self.world > 1 and dist.get_backend(self.pg) == "nccl"     # AVG exists in RCCL only; gloo sums, then / world
+        self._avg_op = dist.ReduceOp.AVG if (self.on_gpu and nccl) else dist.ReduceOp.SUM
 
     # ------------------------------------------------------------------------------------------
     def sync_buffers(self):
