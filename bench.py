@@ -140,6 +140,9 @@ def gpu_leg(args, rank, world, local_rank):
     L.check(lib.hs_prof_collect(fl, ms, cnt), "hs_prof_collect")
     lib.hs_prof_enable(0)
     fence()
+    bracket_us = C.c_float(0.0)   # what the event bracket costs around an empty kernel (reported, not subtracted)
+    L.check(lib.hs_prof_calibrate(C.c_void_p(torch.cuda.current_stream().cuda_stream), 200, C.byref(bracket_us)),
+            "hs_prof_calibrate")
     fam_flops = fl[0] + fl[1]
     fam_ms = ms[0] + ms[1]
     fam_launches = cnt[0] + cnt[1]
@@ -162,7 +165,9 @@ def gpu_leg(args, rank, world, local_rank):
         "kernel_ms_per_step": round(fam_ms / prof_steps, 3),
         "algorithmic_tflop_per_step": round(fam_flops / prof_steps / 1e12, 3),
         "traffic_unit": "bytes per launch (PMC, separate passes)", "traffic_source": traffic_src,
-        "timing": "HIP events around every launch of the family on its own stream, 2 steps run without stream overlap",
+        "timing": "HIP events around every launch of the family on its own stream, 2 steps run without stream overlap; "
+                  "the same bracket around an empty kernel reads event_bracket_us (not subtracted from avg_launch_us)",
+        "event_bracket_us": round(bracket_us.value, 2),
         "split": {"gemm": {"tflops": round(fl[0] / max(ms[0], 1e-9) / 1e9, 1), "ms_per_step": round(ms[0] / prof_steps, 3)},
                   "conv": {"tflops": round(fl[1] / max(ms[1], 1e-9) / 1e9, 1), "ms_per_step": round(ms[1] / prof_steps, 3)}},
     }

@@ -124,6 +124,9 @@ hs_status hs_prof_collect(double* flops, double* ms, int64_t* launches);
 /* measurement only: append one CSV line per recorded launch (class, operand combo, tile cfg, M, N, K, batch, split_k,
    filter R, stride, milliseconds) to `path` and clear the records. */
 hs_status hs_prof_dump(const char* path);
+/* measurement only: mean elapsed time (us) of `n` empty kernels inside the profiler's event bracket, i.e. what the
+   bracket adds to every timed launch. */
+hs_status hs_prof_calibrate(void* stream, int32_t n, float* avg_us);
 
 /* ------------------------------------------------------------------------------------------- */
 /* BatchNorm2d over NHWC activations viewed as [M = N*H*W][C]                                    */

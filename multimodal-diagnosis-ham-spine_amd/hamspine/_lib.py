@@ -195,6 +195,7 @@ def _declare(l):
     l.hs_linear_bwd_ws_bytes.restype = i64
     l.hs_prof_dump.argtypes = [C.c_char_p]
     l.hs_set_overlap.argtypes = [i32]
+    l.hs_prof_calibrate.argtypes = [vp, i32, C.POINTER(C.c_float)]
     l.hs_set_overlap.restype = None
     l.hs_dwconv_ws_bytes.argtypes = [i32] * 5
     l.hs_dwconv_ws_bytes.restype = i64

@@ -60,6 +60,8 @@ static void prof_end(hipStream_t s, ProfRec& r) {
     g_prof.push_back(r);
 }
 
+__global__ void null_kernel() {}
+
 static int g_dbg_cfg = -1, g_dbg_ablate = 0;   // measurement overrides (hs_gemm_debug)
 
 static int combo_of(int ak, int bk) {
@@ -291,6 +293,34 @@ hs_status hs_prof_collect(double* flops, double* ms, int64_t* launches) {
         hs::g_prof_pool.emplace_back(r.a, r.b);
     }
     hs::g_prof.clear();
+    return HS_OK;
+}
+/* measurement only: what the event bracket itself costs.  Launches `n` empty kernels on `stream`, each between the same
+   two event records the profiler puts around a GEMM launch, and returns the mean elapsed time in microseconds (an empty
+   kernel runs for ~2 us; the rest is dispatch latency the bracket adds to every timed launch). */
+hs_status hs_prof_calibrate(void* stream, int32_t n, float* avg_us) {
+    HS_REQUIRE(n > 0 && avg_us, "hs_prof_calibrate: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev(n);
+    for (auto& e : ev) {
+        HS_CHECK_HIP(hipEventCreate(&e.first));
+        HS_CHECK_HIP(hipEventCreate(&e.second));
+    }
+    for (auto& e : ev) {
+        HS_CHECK_HIP(hipEventRecord(e.first, s));
+        hipLaunchKernelGGL(hs::null_kernel, dim3(1), dim3(64), 0, s);
+        HS_CHECK_HIP(hipEventRecord(e.second, s));
+    }
+    HS_CHECK_HIP(hipStreamSynchronize(s));
+    double tot = 0;
+    for (auto& e : ev) {
+        float t = 0.f;
+        HS_CHECK_HIP(hipEventElapsedTime(&t, e.first, e.second));
+        tot += t;
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    *avg_us = (float)(tot / n * 1e3);
     return HS_OK;
 }
 /* Synchronises, appends one CSV line per recorded launch (cls,combo,cfg,M,N,K,batch,split,R,stride,ms) to `path`, clears. */
