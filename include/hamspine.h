@@ -268,6 +268,10 @@ hs_status hs_select_token_bwd(int32_t dtype, const float* dy, void* dx, int32_t 
 /* out[r] = [a[r] | b[r]] and its inverse (torch.cat(dim=1): fusion_blocks.py:186, model_resnet.py:59). */
 hs_status hs_concat2(const float* a, int32_t Ha, const float* b, int32_t Hb, float* out, int64_t rows, void* stream);
 hs_status hs_split2(const float* g, float* da, int32_t Ha, float* db, int32_t Hb, int64_t rows, void* stream);
+/* the same on token tensors of either element type (global/local token concat, reference model.py:311-313). */
+hs_status hs_concat2_t(int32_t dtype, const void* a, int32_t Ha, const void* b, int32_t Hb, void* out, int64_t rows,
+                       void* stream);
+hs_status hs_split2_t(int32_t dtype, const void* g, void* da, int32_t Ha, void* db, int32_t Hb, int64_t rows, void* stream);
 /* out = a*b; b_mode 0: same shape, 1: b is (rows,1), 2: b is a scalar. */
 hs_status hs_mul(const float* a, const float* b, float* out, int64_t rows, int32_t cols, int32_t b_mode, void* stream);
 hs_status hs_rowdot(const float* a, const float* b, float* out, int32_t rows, int32_t cols, void* stream);
@@ -291,6 +295,20 @@ hs_status hs_focal_loss(const float* logits, const int64_t* labels, const float*
    (reference model.py:292-301). */
 hs_status hs_center_crop_resize(const float* x, float* out, int32_t N, int32_t Cc, int32_t H, int32_t W, int32_t y0,
                                 int32_t x0, int32_t ch, int32_t cw, void* stream);
+
+/* LSTM / GRU cells of the slice-sequence encoder (reference modules/sequence_blocks.py:22-34,58-62 -> torch.nn.LSTM /
+   nn.GRU), f32.  gx = x W_ih^T + b_ih and gh = h W_hh^T + b_hh come from hs_linear_fwd (row pitches ldx / ldh); gate order
+   as torch (LSTM i,f,g,o; GRU r,z,n).  `act` [B][4H] keeps the activated gates for the backward. */
+hs_status hs_lstm_cell_fwd(const float* gx, int32_t ldx, const float* gh, int32_t ldh, const float* c_prev, float* h, float* c,
+                           float* act, int32_t B, int32_t H, void* stream);
+/* dgates [B][4H] is the gradient of (gx + gh); dh / dc may be NULL (= zero). */
+hs_status hs_lstm_cell_bwd(const float* dh, const float* dc, const float* act, const float* c_prev, const float* c,
+                           float* dgates, float* dc_prev, int32_t B, int32_t H, void* stream);
+hs_status hs_gru_cell_fwd(const float* gx, int32_t ldx, const float* gh, int32_t ldh, const float* h_prev, float* h,
+                          float* act, int32_t B, int32_t H, void* stream);
+/* dgx / dgh [B][3H]: gradients of gx and gh; dh_prev: the direct z*dh path only (the W_hh path comes from dgh). */
+hs_status hs_gru_cell_bwd(const float* dh, const float* act, const float* h_prev, float* dgx, float* dgh, float* dh_prev,
+                          int32_t B, int32_t H, void* stream);
 
 /* SupConLoss(temperature) on (B, D) features, mean over anchors, loss + d/d features
    (reference scripts/train.py:23-44).  ws: hs_supcon_ws_bytes(B, D). */

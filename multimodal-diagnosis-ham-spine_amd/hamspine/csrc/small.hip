@@ -32,8 +32,9 @@ __global__ void select_token_bwd_kernel(const float* __restrict__ dy, T* __restr
     }
 }
 // out[r] = [a[r] | b[r]]
-__global__ void concat2_kernel(const float* __restrict__ a, int Ha, const float* __restrict__ b, int Hb,
-                               float* __restrict__ o, long long rows) {
+template <typename T>
+__global__ void concat2_kernel(const T* __restrict__ a, int Ha, const T* __restrict__ b, int Hb,
+                               T* __restrict__ o, long long rows) {
     const int H = Ha + Hb;
     const long long n = rows * H;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -42,7 +43,8 @@ __global__ void concat2_kernel(const float* __restrict__ a, int Ha, const float*
         o[i] = c < Ha ? a[r * Ha + c] : b[r * Hb + (c - Ha)];
     }
 }
-__global__ void split2_kernel(const float* __restrict__ g, float* __restrict__ da, int Ha, float* __restrict__ db, int Hb,
+template <typename T>
+__global__ void split2_kernel(const T* __restrict__ g, T* __restrict__ da, int Ha, T* __restrict__ db, int Hb,
                               long long rows) {
     const int H = Ha + Hb;
     const long long n = rows * H;
@@ -301,6 +303,89 @@ __global__ void crop_resize_kernel(const float* __restrict__ x, float* __restric
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// LSTM / GRU cells of the slice-sequence encoder (reference modules/sequence_blocks.py:22-34,58-62 -> torch.nn.LSTM /
+// nn.GRU).  The two matmuls of a step (x W_ih^T + b_ih for all steps at once, h W_hh^T + b_hh per step) run on the GEMM
+// core; these kernels fuse the gate arithmetic.  f32, gate order as torch: LSTM i,f,g,o; GRU r,z,n.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// gx, gh: [B][4H] with row pitches ldx / ldh; c_prev [B][H]; outputs h, c [B][H] and the activated gates [B][4H]
+__global__ void lstm_cell_fwd_kernel(const float* __restrict__ gx, int ldx, const float* __restrict__ gh, int ldh,
+                                     const float* __restrict__ c_prev, float* __restrict__ h, float* __restrict__ c,
+                                     float* __restrict__ act, int B, int H) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, j = i - b * H;
+    const float* x = gx + (long long)b * ldx;
+    const float* r = gh + (long long)b * ldh;
+    const float ig = sigmoidf_(x[j] + r[j]);
+    const float fg = sigmoidf_(x[H + j] + r[H + j]);
+    const float gg = tanhf(x[2 * H + j] + r[2 * H + j]);
+    const float og = sigmoidf_(x[3 * H + j] + r[3 * H + j]);
+    const float cn = fg * c_prev[i] + ig * gg;
+    c[i] = cn;
+    h[i] = og * tanhf(cn);
+    float* a = act + (long long)b * 4 * H;
+    a[j] = ig; a[H + j] = fg; a[2 * H + j] = gg; a[3 * H + j] = og;
+}
+// dgates [B][4H] (pre-activation gradient, shared by the x and h paths), dc_prev [B][H]
+__global__ void lstm_cell_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dc_in,
+                                     const float* __restrict__ act, const float* __restrict__ c_prev,
+                                     const float* __restrict__ c, float* __restrict__ dgates, float* __restrict__ dc_prev,
+                                     int B, int H) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, j = i - b * H;
+    const float* a = act + (long long)b * 4 * H;
+    const float ig = a[j], fg = a[H + j], gg = a[2 * H + j], og = a[3 * H + j];
+    const float tc = tanhf(c[i]);
+    const float g_h = dh ? dh[i] : 0.f;
+    const float dcn = (dc_in ? dc_in[i] : 0.f) + g_h * og * (1.f - tc * tc);
+    float* d = dgates + (long long)b * 4 * H;
+    d[j] = dcn * gg * ig * (1.f - ig);
+    d[H + j] = dcn * c_prev[i] * fg * (1.f - fg);
+    d[2 * H + j] = dcn * ig * (1.f - gg * gg);
+    d[3 * H + j] = g_h * tc * og * (1.f - og);
+    dc_prev[i] = dcn * fg;
+}
+// GRU: gx, gh [B][3H]; saves r, z, n and hn = (W_hn h + b_hn) in act [B][4H]
+__global__ void gru_cell_fwd_kernel(const float* __restrict__ gx, int ldx, const float* __restrict__ gh, int ldh,
+                                    const float* __restrict__ h_prev, float* __restrict__ h, float* __restrict__ act, int B,
+                                    int H) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, j = i - b * H;
+    const float* x = gx + (long long)b * ldx;
+    const float* r_ = gh + (long long)b * ldh;
+    const float rg = sigmoidf_(x[j] + r_[j]);
+    const float zg = sigmoidf_(x[H + j] + r_[H + j]);
+    const float hn = r_[2 * H + j];
+    const float ng = tanhf(x[2 * H + j] + rg * hn);
+    h[i] = (1.f - zg) * ng + zg * h_prev[i];
+    float* a = act + (long long)b * 4 * H;
+    a[j] = rg; a[H + j] = zg; a[2 * H + j] = ng; a[3 * H + j] = hn;
+}
+// dgx [B][3H] (gradient of x W_ih^T + b_ih), dgh [B][3H] (gradient of h W_hh^T + b_hh), dh_prev direct part [B][H]
+__global__ void gru_cell_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ act,
+                                    const float* __restrict__ h_prev, float* __restrict__ dgx, float* __restrict__ dgh,
+                                    float* __restrict__ dh_prev, int B, int H) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, j = i - b * H;
+    const float* a = act + (long long)b * 4 * H;
+    const float rg = a[j], zg = a[H + j], ng = a[2 * H + j], hn = a[3 * H + j];
+    const float g = dh[i];
+    const float dn = g * (1.f - zg) * (1.f - ng * ng);
+    const float dz = g * (h_prev[i] - ng) * zg * (1.f - zg);
+    const float dr = dn * hn * rg * (1.f - rg);
+    float* dx = dgx + (long long)b * 3 * H;
+    float* dhh = dgh + (long long)b * 3 * H;
+    dx[j] = dr; dx[H + j] = dz; dx[2 * H + j] = dn;
+    dhh[j] = dr; dhh[H + j] = dz; dhh[2 * H + j] = dn * rg;
+    dh_prev[i] = g * zg;
+}
 }  // namespace hs
 
 using namespace hs;
@@ -333,15 +418,38 @@ hs_status hs_select_token_bwd(int32_t dtype, const float* dy, void* dx, int32_t 
 }
 hs_status hs_concat2(const float* a, int32_t Ha, const float* b, int32_t Hb, float* out, int64_t rows, void* stream) {
     HS_REQUIRE(a && b && out, "concat2: null argument");
-    hipLaunchKernelGGL(concat2_kernel, dim3(grid_for(rows * (Ha + Hb))), dim3(256), 0, (hipStream_t)stream, a, Ha, b, Hb, out,
-                       rows);
+    hipLaunchKernelGGL(concat2_kernel<float>, dim3(grid_for(rows * (Ha + Hb))), dim3(256), 0, (hipStream_t)stream, a, Ha, b, Hb,
+                       out, rows);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_concat2_t(int32_t dtype, const void* a, int32_t Ha, const void* b, int32_t Hb, void* out, int64_t rows,
+                       void* stream) {
+    HS_REQUIRE(a && b && out, "concat2: null argument");
+    if (dtype == HS_BF16)
+        hipLaunchKernelGGL(concat2_kernel<bf16_t>, dim3(grid_for(rows * (Ha + Hb))), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)a, Ha, (const bf16_t*)b, Hb, (bf16_t*)out, rows);
+    else
+        hipLaunchKernelGGL(concat2_kernel<float>, dim3(grid_for(rows * (Ha + Hb))), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)a, Ha, (const float*)b, Hb, (float*)out, rows);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_split2_t(int32_t dtype, const void* g, void* da, int32_t Ha, void* db, int32_t Hb, int64_t rows, void* stream) {
+    HS_REQUIRE(g, "split2: null argument");
+    if (dtype == HS_BF16)
+        hipLaunchKernelGGL(split2_kernel<bf16_t>, dim3(grid_for(rows * (Ha + Hb))), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)g, (bf16_t*)da, Ha, (bf16_t*)db, Hb, rows);
+    else
+        hipLaunchKernelGGL(split2_kernel<float>, dim3(grid_for(rows * (Ha + Hb))), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)g, (float*)da, Ha, (float*)db, Hb, rows);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
 hs_status hs_split2(const float* g, float* da, int32_t Ha, float* db, int32_t Hb, int64_t rows, void* stream) {
     HS_REQUIRE(g, "split2: null argument");
-    hipLaunchKernelGGL(split2_kernel, dim3(grid_for(rows * (Ha + Hb))), dim3(256), 0, (hipStream_t)stream, g, da, Ha, db, Hb,
-                       rows);
+    hipLaunchKernelGGL(split2_kernel<float>, dim3(grid_for(rows * (Ha + Hb))), dim3(256), 0, (hipStream_t)stream, g, da, Ha, db,
+                       Hb, rows);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
@@ -408,6 +516,39 @@ hs_status hs_center_crop_resize(const float* x, float* out, int32_t N, int32_t C
     const long long n = (long long)N * Cc * H * W;
     hipLaunchKernelGGL(crop_resize_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, x, out, N * Cc, H, W,
                        y0, x0, ch, cw, H, W);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+
+hs_status hs_lstm_cell_fwd(const float* gx, int32_t ldx, const float* gh, int32_t ldh, const float* c_prev, float* h, float* c,
+                           float* act, int32_t B, int32_t H, void* stream) {
+    HS_REQUIRE(gx && gh && c_prev && h && c && act && B > 0 && H > 0, "lstm_cell_fwd: bad argument");
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(ceil_div(B * H, 256)), dim3(256), 0, (hipStream_t)stream, gx, ldx, gh, ldh,
+                       c_prev, h, c, act, B, H);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_lstm_cell_bwd(const float* dh, const float* dc, const float* act, const float* c_prev, const float* c,
+                           float* dgates, float* dc_prev, int32_t B, int32_t H, void* stream) {
+    HS_REQUIRE(act && c_prev && c && dgates && dc_prev && B > 0 && H > 0, "lstm_cell_bwd: bad argument");
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(ceil_div(B * H, 256)), dim3(256), 0, (hipStream_t)stream, dh, dc, act,
+                       c_prev, c, dgates, dc_prev, B, H);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_gru_cell_fwd(const float* gx, int32_t ldx, const float* gh, int32_t ldh, const float* h_prev, float* h,
+                          float* act, int32_t B, int32_t H, void* stream) {
+    HS_REQUIRE(gx && gh && h_prev && h && act && B > 0 && H > 0, "gru_cell_fwd: bad argument");
+    hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3(ceil_div(B * H, 256)), dim3(256), 0, (hipStream_t)stream, gx, ldx, gh, ldh,
+                       h_prev, h, act, B, H);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_gru_cell_bwd(const float* dh, const float* act, const float* h_prev, float* dgx, float* dgh, float* dh_prev,
+                          int32_t B, int32_t H, void* stream) {
+    HS_REQUIRE(dh && act && h_prev && dgx && dgh && dh_prev && B > 0 && H > 0, "gru_cell_bwd: bad argument");
+    hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3(ceil_div(B * H, 256)), dim3(256), 0, (hipStream_t)stream, dh, act, h_prev,
+                       dgx, dgh, dh_prev, B, H);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }

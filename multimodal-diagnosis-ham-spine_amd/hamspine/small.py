@@ -264,6 +264,39 @@ def select_token(x, t=0):
     return SelectTokenFn.apply(x, int(t))
 
 
+class ConcatTokensFn(Function):
+    """[a | b] along the last dim for activations of the compute dtype (bf16 or f32)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        rt.need_gpu(a, b)
+        a, b = a.contiguous(), b.contiguous()
+        if a.dtype != b.dtype:
+            b = b.to(a.dtype)
+        rows = a.numel() // a.shape[-1]
+        Ha, Hb = a.shape[-1], b.shape[-1]
+        o = torch.empty(a.shape[:-1] + (Ha + Hb,), dtype=a.dtype, device=a.device)
+        L.check(_l().hs_concat2_t(rt.hs_dtype(a), rt.p(a), Ha, rt.p(b), Hb, rt.p(o), rows, rt.stream()), "hs_concat2_t")
+        ctx.meta = (a.shape, b.shape, a.dtype)
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        sa, sb, dt = ctx.meta
+        g = g.contiguous()
+        if g.dtype != dt:
+            g = g.to(dt)
+        da = torch.empty(sa, dtype=dt, device=g.device) if ctx.needs_input_grad[0] else None
+        db = torch.empty(sb, dtype=dt, device=g.device) if ctx.needs_input_grad[1] else None
+        rows = g.numel() // g.shape[-1]
+        L.check(_l().hs_split2_t(rt.hs_dtype(dt), rt.p(g), rt.p(da), sa[-1], rt.p(db), sb[-1], rows, rt.stream()), "hs_split2_t")
+        return da, db
+
+
+def concat_tokens(a, b):
+    return ConcatTokensFn.apply(a, b)
+
+
 def concat2(a, b):
     return Concat2Fn.apply(a, b)
 

@@ -4,6 +4,7 @@
 import torch
 import torch.nn as nn
 
+import hamspine
 from encoder import ImageEncoder, TextEncoder
 from hamspine import functional as F
 from hamspine import rt
@@ -171,14 +172,25 @@ class MultimodalBaselineModel(nn.Module):
                 raise ValueError("global/local token types must match.")
             return {k: F.axpby(global_tokens[k], local_tokens[k], 0.5, 0.5) for k in global_tokens}
         if self.global_local_combine == "concat":
-            raise NotImplementedError("global_local_combine='concat' on token tensors is not implemented yet")
+            return self.global_local_proj(S.concat_tokens(global_tokens, local_tokens))
         return F.axpby(global_tokens, local_tokens, 0.5, 0.5)
 
     def _encode_image_tokens(self, image_input):
         if image_input.dim() == 5:
             if not self.sequence_enabled:
                 raise ValueError("Sequence input provided but sequence encoder is disabled.")
-            raise NotImplementedError("5-D slice-sequence inputs need the SequenceEncoder (not implemented)")
+            batch_size, seq_len = image_input.size(0), image_input.size(1)
+            flat = image_input.reshape(batch_size * seq_len, *image_input.shape[2:])
+            tokens = self.image_encoder(flat)
+            if self.global_local_enabled:
+                local_tokens = self.image_encoder(self._center_crop(flat, self.global_local_crop_ratio))
+                tokens = self._combine_tokens(tokens, local_tokens)
+            pooled = self._pool_image_tokens(tokens)                        # (B*T, H) f32
+            seq_encoded = self.sequence_proj(self.sequence_encoder(pooled.reshape(batch_size, seq_len, -1)))
+            seq_tokens = seq_encoded.unsqueeze(1)                           # one image token per study, (B, 1, H)
+            if seq_tokens.dtype != hamspine.compute_dtype():                # token tensors live in the compute dtype
+                seq_tokens = F.axpby(seq_tokens, None, 1.0, 0.0, hamspine.compute_dtype())
+            return seq_tokens, seq_encoded
         tokens = self.image_encoder(image_input)
         if self.global_local_enabled:
             local_tokens = self.image_encoder(self._center_crop(image_input, self.global_local_crop_ratio))

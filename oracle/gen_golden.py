@@ -208,13 +208,33 @@ def gen_e2e_baseline(tmp):
         "e2e_gate_globallocal": dict(fusion_type="basic", classifier_type="mlp", gate_enabled=True, gate_hidden_dim=32,
                                      global_local_enabled=True, global_local_crop_ratio=0.6),
         "e2e_hadamard_imageonly": dict(fusion_type="hadamard", classifier_type="mlp"),
+        "e2e_globallocal_concat": dict(fusion_type="basic", classifier_type="residual", global_local_enabled=True,
+                                       global_local_crop_ratio=0.5, global_local_combine="concat"),
+        # 5-D slice sequences (B, T, 3, H, W): per-slice tower -> SequenceEncoder -> one image token
+        "e2e_sequence_lstm": dict(fusion_type="basic", classifier_type="mlp", sequence_enabled=True, sequence_type="lstm",
+                                  sequence_hidden_dim=32, sequence_bidirectional=True, sequence_dropout=0.0),
+        "e2e_sequence_gru2": dict(fusion_type="concat", classifier_type="mlp", sequence_enabled=True, sequence_type="gru",
+                                  sequence_hidden_dim=64, sequence_num_layers=2, sequence_bidirectional=False,
+                                  sequence_dropout=0.0),
+        "e2e_sequence_transformer": dict(fusion_type="multiscale", classifier_type="mlp", sequence_enabled=True,
+                                         sequence_type="transformer", sequence_hidden_dim=32, sequence_num_layers=2,
+                                         sequence_dropout=0.0, sequence_num_heads=4),
     }
+    seq_images = rnd((2, 3, 3, 64, 64), 83)
     crit = torch.nn.CrossEntropyLoss(label_smoothing=0.02)
     for i, (name, kw) in enumerate(cases.items()):
         m = ref_model.MultimodalBaselineModel(**common, **kw)
         load_procedural(m, SEED + 100 + i)
         m.train()
         t = tab if kw.get("tabular_enabled") else None
+        if kw.get("sequence_enabled"):
+            logits = m.classifier(m.forward_features(seq_images, ids[:2], mask[:2]))
+            e2e_store(name, m, logits, crit(logits, labels[:2]))
+            m.eval()
+            with torch.no_grad():
+                ev = m(seq_images, ids[:2], mask[:2])
+            np.savez_compressed(os.path.join(OUT, name + "_eval.npz"), logits=ev.numpy())
+            continue
         if name == "e2e_hadamard_imageonly":
             logits = m(images, ids, mask, tabular_input=t, ablation_mode="image_only")
         elif kw.get("gate_enabled"):

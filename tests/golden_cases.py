@@ -110,13 +110,29 @@ E2E_CASES = {
     "e2e_gate_globallocal": (SEED + 104, dict(fusion_type="basic", classifier_type="mlp", gate_enabled=True,
                                               gate_hidden_dim=32, global_local_enabled=True, global_local_crop_ratio=0.6)),
     "e2e_hadamard_imageonly": (SEED + 105, dict(fusion_type="hadamard", classifier_type="mlp")),
+    "e2e_globallocal_concat": (SEED + 106, dict(fusion_type="basic", classifier_type="residual", global_local_enabled=True,
+                                                global_local_crop_ratio=0.5, global_local_combine="concat")),
+    "e2e_sequence_lstm": (SEED + 107, dict(fusion_type="basic", classifier_type="mlp", sequence_enabled=True,
+                                           sequence_type="lstm", sequence_hidden_dim=32, sequence_bidirectional=True,
+                                           sequence_dropout=0.0)),
+    "e2e_sequence_gru2": (SEED + 108, dict(fusion_type="concat", classifier_type="mlp", sequence_enabled=True,
+                                           sequence_type="gru", sequence_hidden_dim=64, sequence_num_layers=2,
+                                           sequence_bidirectional=False, sequence_dropout=0.0)),
+    "e2e_sequence_transformer": (SEED + 109, dict(fusion_type="multiscale", classifier_type="mlp", sequence_enabled=True,
+                                                  sequence_type="transformer", sequence_hidden_dim=32,
+                                                  sequence_num_layers=2, sequence_dropout=0.0, sequence_num_heads=4)),
 }
 
 
-def e2e_inputs():
+def e2e_inputs(kw=None):
+    """(images, ids, mask, labels, tabular) of an end-to-end case; sequence cases take (2, T=3, 3, 64, 64) slices and the
+    first two rows of ids / mask / labels (oracle/gen_golden.py: seq_images)"""
     from oracle.procedural import synthetic_batch
     images, ids, mask, labels = synthetic_batch(4, 64, 24, TINY_BERT["vocab_size"], 7, seed=81, min_len=3)
     tab = torch.randn((4, 9), generator=torch.Generator().manual_seed(82))
+    if kw and kw.get("sequence_enabled"):
+        images = torch.randn((2, 3, 3, 64, 64), generator=torch.Generator().manual_seed(83))
+        ids, mask, labels, tab = ids[:2], mask[:2], labels[:2], tab[:2]
     return images, ids, mask, labels, tab
 
 
@@ -150,6 +166,8 @@ def e2e_forward(model, name, kw, images, ids, mask, tab):
         return model(images, ids, mask, tabular_input=t, ablation_mode="image_only")
     if kw.get("gate_enabled"):
         return model(images, ids, mask, tabular_input=t)
+    if kw.get("sequence_enabled"):
+        return model.classifier(model.forward_features(images, ids, mask))
     return model.classifier(model.forward_features(images, ids, mask, tabular_input=t))
 
 

@@ -96,7 +96,7 @@ def test_oracle_bert_matches_installed_transformers():
 def test_oracle_e2e_matches_reference_vectors(name):
     seed, kw = gc.E2E_CASES[name]
     fx = gc.load(name)
-    images, ids, mask, labels, tab = gc.e2e_inputs()
+    images, ids, mask, labels, tab = gc.e2e_inputs(kw)
     m = om.OMultimodalBaselineModel(bert_cfg=gc.TINY_BERT, **gc.E2E_COMMON, **kw)
     load_procedural(m, seed).train()
     logits = gc.e2e_forward(m, name, kw, images, ids, mask, tab)

@@ -215,7 +215,7 @@ def test_e2e_baseline_matches_reference_vectors(name, tmp_path):
     from hamspine import functional as F
     seed, kw = gc.E2E_CASES[name]
     fx = gc.load(name)
-    images, ids, mask, labels, tab = [t.to(DEV) for t in gc.e2e_inputs()]
+    images, ids, mask, labels, tab = [t.to(DEV) for t in gc.e2e_inputs(kw)]
     m = _build_product_e2e(kw, tmp_path, seed).train()
     logits = gc.e2e_forward(m, name, kw, images, ids, mask, tab)
     assert logits.dtype == torch.float32
@@ -231,7 +231,7 @@ def test_e2e_baseline_matches_reference_vectors(name, tmp_path):
     # max(1e-2 * |g|_2, 5 x the reference-f32-vs-f64 gap of that parameter)  (single residual blocks are held to
     # 1e-3 on every gradient in test_residual_block_well_conditioned; here 20 BN layers at 16 samples/channel stack up).
     o64 = load_procedural(om.OMultimodalBaselineModel(bert_cfg=gc.TINY_BERT, **gc.E2E_COMMON, **kw), seed).double().train()
-    c_im, c_ids, c_mask, c_lab, c_tab = gc.e2e_inputs()
+    c_im, c_ids, c_mask, c_lab, c_tab = gc.e2e_inputs(kw)
     lg64 = gc.e2e_forward(o64, name, kw, c_im.double(), c_ids, c_mask, c_tab.double())
     torch.nn.functional.cross_entropy(lg64, c_lab, label_smoothing=0.02).backward()
     g64 = {k: p.grad for k, p in o64.named_parameters() if p.grad is not None}
@@ -284,7 +284,7 @@ def test_e2e_bf16_mode_close_to_reference(tmp_path):
     name = "e2e_basic_mlp"
     seed, kw = gc.E2E_CASES[name]
     fx = gc.load(name)
-    images, ids, mask, labels, tab = [t.to(DEV) for t in gc.e2e_inputs()]
+    images, ids, mask, labels, tab = [t.to(DEV) for t in gc.e2e_inputs(kw)]
     hamspine.set_compute_dtype("bf16")
     m = _build_product_e2e(kw, tmp_path, seed).train()
     logits = gc.e2e_forward(m, name, kw, images, ids, mask, tab)
@@ -314,7 +314,7 @@ def test_state_dict_roundtrip_and_hooks(tmp_path):
           m.image_encoder.layer4[-1].register_forward_hook(lambda mod, i, out: seen.__setitem__("l4", out)),
           m.fusion.register_forward_hook(lambda mod, i, out: seen.__setitem__("fusion", out)),
           m.image_encoder.layer4[-1].register_full_backward_hook(lambda mod, gi, go: seen.__setitem__("g4", go[0]))]
-    images, ids, mask, labels, tab = [t.to(DEV) for t in gc.e2e_inputs()]
+    images, ids, mask, labels, tab = [t.to(DEV) for t in gc.e2e_inputs(kw)]
     m.eval()
     logits = m(images, ids, mask)
     logits[:, 0].sum().backward()
