@@ -240,14 +240,14 @@ def test_e2e_baseline_matches_reference_vectors(name, tmp_path):
         n64 = g64[k].norm().item()
         gap = abs(n.item() - n64)
         err = abs(params[k].grad.double().norm().item() - n64)
-        assert err <= max(1e-2 * n64, 5 * gap) + 1e-6, f"{name}: |grad {k}| err {err:.3e} (ref gap {gap:.3e}, norm {n64:.3e})"
+        assert err <= max(2e-2 * n64, 5 * gap) + 1e-6, f"{name}: |grad {k}| err {err:.3e} (ref gap {gap:.3e}, norm {n64:.3e})"
     for k, g in fx["gw"].items():
         # relative L2 per parameter: a single ReLU / max-pool tie flipping between two f32 evaluations moves one
         # channel's BN-bias gradient by ~1/M of its value, which a max-abs metric would flag
         scale = g64[k].norm().item()
         gap = (g.double() - g64[k]).norm().item()
         err = (params[k].grad.double().cpu() - g64[k]).norm().item()
-        assert err <= max(1e-2 * scale, 5 * gap) + 1e-6, f"{name}: grad {k} L2 err {err:.3e} (ref gap {gap:.3e}, norm {scale:.3e})"
+        assert err <= max(2e-2 * scale, 5 * gap) + 1e-6, f"{name}: grad {k} L2 err {err:.3e} (ref gap {gap:.3e}, norm {scale:.3e})"
     nograd = sorted(k for k, p in params.items() if p.grad is None)
     assert nograd == sorted(str(s) for s in fx["nograd"])
     m.eval()
@@ -444,3 +444,28 @@ def test_fused_adamw_matches_torch():
         o_got.step()
     for r, q in zip(ref, got):
         _close(q, r, "adamw param", 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("kind,layers,bi", [("lstm", 1, True), ("lstm", 2, False), ("gru", 1, True), ("gru", 2, True),
+                                            ("transformer", 2, True)])
+def test_sequence_encoder_matches_oracle(kind, layers, bi):
+    """SequenceEncoder alone (reference modules/sequence_blocks.py) against the oracle built on torch.nn.LSTM / GRU /
+    TransformerEncoder: output 1e-4, every gradient 1e-3 (f32)."""
+    from modules.sequence_blocks import SequenceEncoder
+    o = load_procedural(om.OSequenceEncoder(64, 32, kind, layers, bi, 0.0, 4), 9).train()
+    p = SequenceEncoder(64, 32, kind, layers, bi, 0.0, 4)
+    p.load_state_dict(o.state_dict(), strict=True)
+    p = p.to(DEV).train()
+    x = torch.randn(3, 5, 64, generator=torch.Generator().manual_seed(1))
+    cot = torch.randn(3, 32, generator=torch.Generator().manual_seed(2))
+    xo = x.clone().requires_grad_(True)
+    yo = o(xo)
+    (yo * cot).sum().backward()
+    xp = x.to(DEV).requires_grad_(True)
+    yp = p(xp)
+    (yp * cot.to(DEV)).sum().backward()
+    _close(yp, yo, f"{kind} out", 1e-4)
+    _close(xp.grad, xo.grad, f"{kind} dx", 1e-3, 1e-6)
+    po = dict(o.named_parameters())
+    for k, q in p.named_parameters():
+        _close(q.grad, po[k].grad, f"{kind} grad {k}", 1e-3, 1e-6)
