@@ -275,6 +275,10 @@ hs_status hs_split2_t(int32_t dtype, const void* g, void* da, int32_t Ha, void* 
 /* out = a*b; b_mode 0: same shape, 1: b is (rows,1), 2: b is a scalar. */
 hs_status hs_mul(const float* a, const float* b, float* out, int64_t rows, int32_t cols, int32_t b_mode, void* stream);
 hs_status hs_rowdot(const float* a, const float* b, float* out, int32_t rows, int32_t cols, void* stream);
+/* out[r] = KL(p[r] || q[r]) on probabilities clamped to [eps, 1] (reference mibf_net/attention.py:25-28).  With w (the
+   incoming gradient per row) dp / dq receive the gradients; out may then be NULL. */
+hs_status hs_kl_rows(const float* p, const float* q, float* out, const float* w, float* dp, float* dq, int32_t rows,
+                     int32_t cols, float eps, void* stream);
 /* out[0] = sum a[i]*b[i] (b NULL: sum a). */
 hs_status hs_dot(const float* a, const float* b, float* out, int64_t n, void* stream);
 hs_status hs_sigmoid_fwd(const float* x, float* out, int64_t n, void* stream);

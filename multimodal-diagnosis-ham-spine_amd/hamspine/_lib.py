@@ -195,6 +195,7 @@ def _declare(l):
     l.hs_linear_bwd_ws_bytes.restype = i64
     l.hs_prof_dump.argtypes = [C.c_char_p]
     l.hs_set_overlap.argtypes = [i32]
+    l.hs_kl_rows.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]
     l.hs_lstm_cell_fwd.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, vp]
     l.hs_lstm_cell_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     l.hs_gru_cell_fwd.argtypes = [vp, i32, vp, i32, vp, vp, vp, i32, i32, vp]

@@ -81,6 +81,28 @@ __global__ void rowdot_kernel(const float* __restrict__ a, const float* __restri
     acc = wave_sum(acc);
     if (lane == 0) o[r] = acc;
 }
+// KL(p || q) per row on probabilities clamped to [eps, 1] (reference mibf_net/attention.py:25-28); one wave per row.
+// dp / dq (optional): gradients of sum_r w[r] * kl[r]; the clamp passes no gradient where it is active.
+__global__ void kl_rows_kernel(const float* __restrict__ p, const float* __restrict__ q, float* __restrict__ o,
+                               const float* __restrict__ w, float* __restrict__ dp, float* __restrict__ dq, int rows,
+                               int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float acc = 0.f;
+    const float wr = w ? w[r] : 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        const long long i = (long long)r * cols + c;
+        const float pr = p[i], qr = q[i];
+        const float pc = fminf(fmaxf(pr, eps), 1.f), qc = fminf(fmaxf(qr, eps), 1.f);
+        const float lp = __logf(pc), lq = __logf(qc);
+        acc += pc * (lp - lq);
+        if (dp) dp[i] = (pr > eps && pr < 1.f) ? wr * (lp - lq + 1.f) : 0.f;
+        if (dq) dq[i] = (qr > eps && qr < 1.f) ? -wr * pc / qc : 0.f;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0 && o) o[r] = acc;
+}
 // out[0] = sum_i a[i]*b[i]  (single block, deterministic)
 __global__ void dot_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, long long n) {
     __shared__ float sh[4];
@@ -463,6 +485,14 @@ hs_status hs_mul(const float* a, const float* b, float* out, int64_t rows, int32
 hs_status hs_rowdot(const float* a, const float* b, float* out, int32_t rows, int32_t cols, void* stream) {
     HS_REQUIRE(a && b && out, "rowdot: null argument");
     hipLaunchKernelGGL(rowdot_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, a, b, out, rows, cols);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_kl_rows(const float* p, const float* q, float* out, const float* w, float* dp, float* dq, int32_t rows,
+                     int32_t cols, float eps, void* stream) {
+    HS_REQUIRE(p && q && rows > 0 && cols > 0 && (out || dp || dq) && (w || (!dp && !dq)), "kl_rows: bad argument");
+    hipLaunchKernelGGL(kl_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, p, q, out, w, dp, dq, rows,
+                       cols, eps);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }

@@ -260,6 +260,37 @@ class FocalLossFn(_LossWithGrads):
         return a, None, None, None
 
 
+class KLRowsFn(Function):
+    """KL(p || q) over the last dim on probabilities clamped to [eps, 1] (reference mibf_net/attention.py:25-28)"""
+
+    @staticmethod
+    def forward(ctx, p, q, eps):
+        p, q = _f32c(p), _f32c(q)
+        cols = p.shape[-1]
+        rows = p.numel() // cols
+        o = torch.empty(p.shape[:-1], dtype=torch.float32, device=p.device)
+        L.check(_l().hs_kl_rows(rt.p(p), rt.p(q), rt.p(o), None, None, None, rows, cols, eps, rt.stream()), "hs_kl_rows")
+        ctx.save_for_backward(p, q)
+        ctx.eps = eps
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        p, q = ctx.saved_tensors
+        cols = p.shape[-1]
+        rows = p.numel() // cols
+        g = _f32c(g)
+        dp = torch.empty_like(p) if ctx.needs_input_grad[0] else None
+        dq = torch.empty_like(q) if ctx.needs_input_grad[1] else None
+        L.check(_l().hs_kl_rows(rt.p(p), rt.p(q), None, rt.p(g), rt.p(dp), rt.p(dq), rows, cols, ctx.eps, rt.stream()),
+                "hs_kl_rows")
+        return dp, dq, None
+
+
+def kl_divergence(p, q, eps=1e-8):
+    return KLRowsFn.apply(p, q, float(eps))
+
+
 def select_token(x, t=0):
     return SelectTokenFn.apply(x, int(t))
 

@@ -1,7 +1,9 @@
 """IBFA operators of MIBF-Net (reference mibf_net/attention.py) on the hamspine f32 kernels."""
 import torch.nn as nn
 
+from hamspine import convnext_ops as X
 from hamspine import functional as F
+from hamspine import small as S
 from hamspine.nn import Linear
 
 
@@ -21,9 +23,9 @@ class SelfAttention(nn.Module):
 
 
 def compute_kl_divergence(p, q, eps=1e-8):
-    """KL(p||q) on clamped probabilities (attention.py:25-28).  The training path uses the fused MP-Loss kernel
-    (hamspine.small.mp_loss); this stand-alone form is kept for API parity and only accepts device tensors."""
-    raise NotImplementedError("use hamspine.small.mp_loss (fused MP-Loss); the stand-alone KL is not exposed")
+    """KL(p||q) over the last dim on clamped probabilities (attention.py:25-28).  The training path uses the fused
+    MP-Loss kernel (hamspine.small.mp_loss); this is the stand-alone operator with the same contract."""
+    return S.kl_divergence(p, q, eps)
 
 
 class MultiHeadCrossAttention_v2(nn.Module):
@@ -42,6 +44,19 @@ class MultiHeadCrossAttention_v2(nn.Module):
         self.to_out = Linear(dim, dim)
 
     def forward(self, x, y):
-        mods = (self.toK_x, self.toQ_x, self.toV_x, self.toK_y, self.toV_y, self.to_out)
-        params = [t for m in mods for t in (m.weight, m.bias)]
-        return F.CrossAttnV2Fn.apply(x, y, self.num_heads, *params)
+        if x.shape[1] == 1 and y.shape[1] == 1:
+            # the shape MIBF-Net produces (model_resnet.py:40-56): one fused node writes the projections straight into the
+            # concatenated key / value buffers
+            mods = (self.toK_x, self.toQ_x, self.toV_x, self.toK_y, self.toV_y, self.to_out)
+            params = [t for m in mods for t in (m.weight, m.bias)]
+            return F.CrossAttnV2Fn.apply(x, y, self.num_heads, *params)
+        # general token counts: keys / values of x and y concatenated along the token axis (attention.py:60-70)
+        b, sx, d = x.shape
+        sy = y.shape[1]
+
+        def cat_tokens(a, c):      # (B, Sx, D) | (B, Sy, D) -> (B, Sx + Sy, D): a last-dim concat of the flattened rows
+            return S.concat2(a.reshape(b, sx * d), c.reshape(b, sy * d)).reshape(b, sx + sy, d)
+        kcat = cat_tokens(self.toK_x(x), self.toK_y(y))
+        vcat = cat_tokens(self.toV_x(x), self.toV_y(y))
+        out = X.attention_core(self.toQ_x(x), kcat, vcat, heads=self.num_heads, scale=1.0 / (self.head_dim ** 0.5))
+        return self.to_out(out)

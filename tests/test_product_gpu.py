@@ -469,3 +469,17 @@ def test_sequence_encoder_matches_oracle(kind, layers, bi):
     po = dict(o.named_parameters())
     for k, q in p.named_parameters():
         _close(q.grad, po[k].grad, f"{kind} grad {k}", 1e-3, 1e-6)
+
+
+def test_kl_divergence_matches_reference_vector_and_oracle_grads():
+    from mibf_net.attention import compute_kl_divergence
+    fx = gc.load("kl_divergence")
+    p, q = fx["p"].to(DEV).requires_grad_(True), fx["q"].to(DEV).requires_grad_(True)
+    kl = compute_kl_divergence(p, q)
+    _close(kl, fx["kl"], "kl", 1e-5)
+    w = torch.randn(kl.shape, generator=torch.Generator().manual_seed(3))
+    (kl * w.to(DEV)).sum().backward()
+    po, qo = fx["p"].clone().requires_grad_(True), fx["q"].clone().requires_grad_(True)
+    (om.okl(po, qo) * w).sum().backward()
+    _close(p.grad, po.grad, "dKL/dp", 1e-4, 1e-6)
+    _close(q.grad, qo.grad, "dKL/dq", 1e-4, 1e-6)
