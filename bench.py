@@ -85,6 +85,8 @@ def gpu_leg(args, rank, world, local_rank):
     if world > 1:
         from hamspine.ddp import DataParallel
         ddp = DataParallel(net)
+    # overlap_backward (updates enqueued while backward runs) measured 17.0 vs 16.7 ms/step here: the HBM-bound update
+    # slows the GEMMs it runs beside by as much as it saves, so the optimizer steps after backward
     opt = FusedAdamW(net.parameters(), lr=1e-4, weight_decay=0.01)
     images, ids, mask, labels = synthetic(rank, device)
 

@@ -15,8 +15,54 @@ from . import rt
 class _FusedAdamBase(torch.optim.Optimizer):
     _decoupled = True
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, overlap_backward=False,
+                 overlap_chunk=8 << 20):
+        """overlap_backward: update parameters while backward is still running -- as soon as `overlap_chunk` elements
+        worth of gradients are final (post-accumulate hooks) their fused update is enqueued on a side stream ordered
+        behind the streams that produced them; step() flushes the rest and joins.  Same arithmetic as stepping after
+        backward; valid whenever nothing between backward and step() reads all gradients at once (no global-norm
+        clipping, no gradient accumulation over several backwards), which is how the reference trains
+        (scripts/train.py:373-385, mibf_net/train_resnet.py:29-33)."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._overlap = bool(overlap_backward)
+        self._chunk = int(overlap_chunk)
+        self._pending, self._pending_n = [], 0
+        self._stream = None
+        self._done = set()
+        if self._overlap:
+            self._group_of = {}
+            for g in self.param_groups:
+                for p in g["params"]:
+                    self._group_of[p] = g
+                    p.register_post_accumulate_grad_hook(self._on_grad)
+
+    # -- optimizer-in-backward -------------------------------------------------------------------------------------
+    def _on_grad(self, p):
+        self._pending.append(p)
+        self._pending_n += p.numel()
+        if self._pending_n >= self._chunk or len(self._pending) >= 96:
+            self._flush()
+
+    @torch.no_grad()
+    def _flush(self):
+        if not self._pending:
+            return
+        ps, self._pending, self._pending_n = self._pending, [], 0
+        dev = ps[0].device
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        self._stream.wait_stream(cur)                       # gradients may come from the ambient or a tower stream
+        for s in rt.side_streams():
+            if s.device == dev and s != cur:
+                self._stream.wait_stream(s)
+        with torch.cuda.stream(self._stream):
+            by_group = {}
+            for p in ps:
+                by_group.setdefault(id(self._group_of[p]), (self._group_of[p], []))[1].append(p)
+            for group, sel in by_group.values():
+                self._update(group, sel, 1.0)
+        self._done.update(ps)
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
@@ -24,49 +70,63 @@ class _FusedAdamBase(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        lib = L.lib()
+        if self._overlap and closure is None and grad_scale == 1.0:
+            self._flush()
+            done, self._done = self._done, set()
+            for group in self.param_groups:                 # parameters whose hook never fired this step (none, normally)
+                rest = [p for p in group["params"] if p.grad is not None and p not in done]
+                if rest:
+                    self._update(group, rest, 1.0)
+            if self._stream is not None:
+                torch.cuda.current_stream(self._stream.device).wait_stream(self._stream)
+            return loss
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.grad is not None]
-            if not ps:
-                continue
-            rt.need_gpu(*ps)
-            # all tensors of a group share the step count (they are created together)
-            steps = set()
-            for p in ps:
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] = int(st["step"]) + 1
-                steps.add(st["step"])
-            b1, b2 = group["betas"]
-            for step in steps:
-                sel = [p for p in ps if self.state[p]["step"] == step]
-                n = len(sel)
-                for p in sel:
-                    if p.dtype != torch.float32 or p.grad.dtype != torch.float32:
-                        raise L.HamspineError("FusedAdam expects f32 parameters and gradients")
-                    # elementwise update: any dense layout works as long as p / grad / state share it
-                    if p.grad.stride() != p.stride():
-                        g2 = torch.empty_like(p, memory_format=torch.preserve_format)
-                        g2.copy_(p.grad)   # rare: a gradient produced outside our nodes in another layout
-                        p.grad = g2
-                arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
-                cnt = (C.c_int64 * n)(*[p.numel() for p in sel])
-                L.check(lib.hs_adam_step_multi(
-                    n, arr(sel), arr([p.grad for p in sel]), arr([self.state[p]["exp_avg"] for p in sel]),
-                    arr([self.state[p]["exp_avg_sq"] for p in sel]), cnt, float(group["lr"]), b1, b2, group["eps"],
-                    group["weight_decay"], step, 1 if self._decoupled else 0, float(grad_scale), rt.stream()),
-                    "hs_adam_step_multi")
+            if ps:
+                self._update(group, ps, grad_scale)
         return loss
+
+    def _update(self, group, ps, grad_scale):
+        """one fused launch (per 32 tensors) for the parameters `ps` of `group`, on the current stream"""
+        if not ps:
+            return
+        lib = L.lib()
+        rt.need_gpu(*ps)
+        steps = set()
+        for p in ps:
+            st = self.state[p]
+            if not st:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] = int(st["step"]) + 1
+            steps.add(st["step"])
+        b1, b2 = group["betas"]
+        for step in steps:          # tensors of a group normally share the step count (they are created together)
+            sel = [p for p in ps if self.state[p]["step"] == step]
+            n = len(sel)
+            for p in sel:
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32:
+                    raise L.HamspineError("FusedAdam expects f32 parameters and gradients")
+                # elementwise update: any dense layout works as long as p / grad / state share it
+                if p.grad.stride() != p.stride():
+                    g2 = torch.empty_like(p, memory_format=torch.preserve_format)
+                    g2.copy_(p.grad)   # rare: a gradient produced outside our nodes in another layout
+                    p.grad = g2
+            arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+            cnt = (C.c_int64 * n)(*[p.numel() for p in sel])
+            L.check(lib.hs_adam_step_multi(
+                n, arr(sel), arr([p.grad for p in sel]), arr([self.state[p]["exp_avg"] for p in sel]),
+                arr([self.state[p]["exp_avg_sq"] for p in sel]), cnt, float(group["lr"]), b1, b2, group["eps"],
+                group["weight_decay"], step, 1 if self._decoupled else 0, float(grad_scale), rt.stream()),
+                "hs_adam_step_multi")
 
 
 class FusedAdamW(_FusedAdamBase):
     _decoupled = True
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
-        super().__init__(params, lr, betas, eps, weight_decay)
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, **kw):
+        super().__init__(params, lr, betas, eps, weight_decay, **kw)
 
 
 class FusedAdam(_FusedAdamBase):

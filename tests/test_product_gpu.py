@@ -483,3 +483,32 @@ def test_kl_divergence_matches_reference_vector_and_oracle_grads():
     (om.okl(po, qo) * w).sum().backward()
     _close(p.grad, po.grad, "dKL/dp", 1e-4, 1e-6)
     _close(q.grad, qo.grad, "dKL/dq", 1e-4, 1e-6)
+
+
+def test_optimizer_in_backward_matches_stepping_after_backward(tmp_path):
+    """FusedAdamW(overlap_backward=True) enqueues updates while backward runs; three training steps must leave the
+    parameters that stepping after backward leaves.  Not bitwise: the word-embedding gradient is a float atomic scatter,
+    so two runs of the SAME configuration already differ in the last bits (measured here as the run-to-run spread)."""
+    from hamspine import functional as F
+    from hamspine.optim import FusedAdamW
+    name = "e2e_multiscale_residual"
+    seed, kw = gc.E2E_CASES[name]
+    images, ids, mask, labels, tab = [t.to(DEV) for t in gc.e2e_inputs(kw)]
+    finals = []
+    for overlap in (False, False, True):
+        m = _build_product_e2e(kw, tmp_path, seed).train()
+        opt = FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.01, overlap_backward=overlap, overlap_chunk=20000)
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = F.cross_entropy(m.classifier(m.forward_features(images, ids, mask)), labels, label_smoothing=0.02)
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        finals.append({k: v.detach().float().clone() for k, v in m.state_dict().items()})
+        assert all(int(opt.state[p]["step"]) == 3 for p in m.parameters() if p in opt.state)
+    a, a2, b = finals
+    for k in a:
+        spread = (a[k] - a2[k]).abs().max().item()
+        err = (a[k] - b[k]).abs().max().item()
+        scale = max(a[k].abs().max().item(), 1e-6)
+        assert err <= 10 * spread + 1e-5 * scale, f"{k}: overlapped vs plain {err:.3e}, run-to-run {spread:.3e}, scale {scale:.3e}"
