@@ -183,7 +183,7 @@ def gpu_leg(args, rank, world, local_rank):
     return dt, final_loss, roofline, nparams
 
 
-def cpu_leg(sample_batch=4, steps=2):
+def cpu_leg(sample_batch=4, steps=24):
     """The oracle's restatement of the same step on the host cores (kind = "port"), bounded sample."""
     from oracle import models as om
     from oracle.procedural import synthetic_batch
