@@ -1,0 +1,128 @@
+"""Two ranks sharing the one card (gloo carries the collectives through host memory): the N>1 path of bench.py with the
+HIP backward nodes writing straight into hamspine.ddp's gradient buckets, the text tower on its own stream and the
+collective stream ordered behind both.  Checks: both ranks end with identical averaged gradients and parameters, and
+the averaged gradients equal the mean of the two single-process gradients."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import golden_cases as gc
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(tmp, seed, kw):
+    import model as product_model
+    from oracle.procedural import load_procedural
+    d = gc.save_bert_dir(gc.TINY_BERT, os.path.join(tmp, "bert"))
+    m = product_model.MultimodalBaselineModel(pretrained_image=False, image_weights_path=None, text_model_name=d,
+                                              **gc.E2E_COMMON, **kw)
+    load_procedural(m, seed)
+    return m.to("cuda").train()
+
+
+def _batch(rank):
+    from oracle.procedural import synthetic_batch
+    return [t.to("cuda") for t in synthetic_batch(4, 64, 24, gc.TINY_BERT["vocab_size"], 7, seed=500 + rank, min_len=3)]
+
+
+def _worker(rank, world, port, tmp, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, os.path.join(ROOT, "multimodal-diagnosis-ham-spine_amd"))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import hamspine
+        from hamspine import functional as F
+        from hamspine.ddp import DataParallel
+        from hamspine.optim import FusedAdamW
+        hamspine.set_compute_dtype("f32")
+        seed, kw = gc.E2E_CASES["e2e_basic_mlp"]
+        net = _build(os.path.join(tmp, f"r{rank}"), seed, kw)
+        ddp = DataParallel(net, bucket_mb=0.25)          # several buckets
+        assert len(ddp.buckets) > 3
+        opt = FusedAdamW(net.parameters(), lr=1e-3, weight_decay=0.0)
+        images, ids, mask, labels = _batch(rank)
+        first = None
+        for it in range(2):
+            opt.zero_grad(set_to_none=True)
+            loss = F.cross_entropy(net.classifier(net.forward_features(images, ids, mask)), labels, label_smoothing=0.02)
+            loss.backward()
+            ddp.finish()
+            grads = {k: p.grad.detach().float().cpu().clone() for k, p in net.named_parameters() if p.grad is not None}
+            if it == 0:
+                first = grads
+            opt.step()
+        torch.cuda.synchronize()
+        params = {k: p.detach().float().cpu().clone() for k, p in net.named_parameters()}
+        nograd = sorted(k for k, p in net.named_parameters() if p.grad is None)
+        as_np = lambda d: {k: v.numpy() for k, v in d.items()}     # by value: the worker exits before the parent reads
+        out.put((rank, "ok", as_np(grads), as_np(params), nograd, as_np(first)))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        out.put((rank, "error: " + repr(e) + traceback.format_exc(), None, None, None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_card_average_gradients(tmp_path):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r = out.get(timeout=600)
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=120)
+    for r in res.values():
+        assert r[1] == "ok", r[1]
+    tt = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}
+    res = {r: (v[0], v[1], tt(v[2]), tt(v[3]), v[4], tt(v[5])) for r, v in res.items()}
+    g0, g1 = res[0][2], res[1][2]
+    assert g0.keys() == g1.keys() and res[0][4] == res[1][4]
+    assert any("pooler" in k for k in res[0][4])              # unused parameters keep grad None on every rank
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), f"averaged gradient differs across ranks: {k}"
+    for k in res[0][3]:
+        assert torch.equal(res[0][3][k], res[1][3][k]), f"parameters diverged: {k}"
+    # the first step's averaged gradients are the mean of the two local gradients (single process, same weights)
+    import hamspine
+    from hamspine import functional as F
+    hamspine.set_compute_dtype("f32")
+    try:
+        seed, kw = gc.E2E_CASES["e2e_basic_mlp"]
+        local = []
+        for rank in range(2):
+            net = _build(str(tmp_path / f"s{rank}"), seed, kw)
+            images, ids, mask, labels = _batch(rank)
+            F.cross_entropy(net.classifier(net.forward_features(images, ids, mask)), labels, label_smoothing=0.02).backward()
+            local.append({k: p.grad.detach().float().cpu() for k, p in net.named_parameters() if p.grad is not None})
+    finally:
+        hamspine.set_compute_dtype("bf16")
+    first = res[0][5]
+    assert local[0].keys() == first.keys()
+    for k in first:
+        want = 0.5 * (local[0][k] + local[1][k])
+        scale = max(want.abs().max().item(), 1e-6)
+        err = (first[k] - want).abs().max().item()
+        assert err <= 2e-5 * scale + 1e-7, f"{k}: averaged gradient {err:.3e} off the mean of the local ones (scale {scale:.3e})"
+    for k, g in g0.items():
+        assert torch.isfinite(g).all(), k
