@@ -209,14 +209,13 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
         if (bf16) cfg = t12864 >= 1536 ? CFG_128x64 : CFG_64x64;
         else cfg = (vec && t128 >= 200) ? CFG_128x128 : CFG_64x64;
     }
-    if (g_dbg_cfg >= 0 && cfg != CFG_STEM && (g_dbg_cfg < 4 || !conv)) cfg = g_dbg_cfg;
-    a.ablate = g_dbg_ablate;
+    if (g_dbg_cfg >= 0 && g_dbg_cfg <= CFG_64x64 && cfg != CFG_STEM) cfg = g_dbg_cfg;
     int BM = 64, BN = 64;
-    if (cfg == CFG_128x128 || cfg == CFG_128x128x32) { BM = 128; BN = 128; }
-    else if (cfg == CFG_128x64 || cfg == CFG_STEM || cfg == CFG_128x64x32) { BM = 128; BN = 64; }
+    if (cfg == CFG_128x128) { BM = 128; BN = 128; }
+    else if (cfg == CFG_128x64 || cfg == CFG_STEM) { BM = 128; BN = 64; }
     a.tiles_m = ceil_div(p->M, BM);
     a.tiles_n = ceil_div(p->N, BN);
-    const int kb_cfg = (cfg == CFG_STEM || cfg == CFG_128x128x32 || cfg == CFG_128x64x32) ? 32 : bk;
+    const int kb_cfg = cfg == CFG_STEM ? 32 : bk;
     {
         // K tiles one workgroup walks -> LDS ring slots it needs (a single-tile 1x1 convolution allocates one slot, so
         // 5-6 workgroups instead of 2 share a CU and hide each other's load -> MFMA -> store latency chain)

@@ -7,8 +7,6 @@ namespace hs {
         case CFG_128x128: L(128, 128, 64, AK, BKD); \
         case CFG_128x64: L(128, 64, 64, AK, BKD);  \
         case CFG_64x64: L(64, 64, 64, AK, BKD);    \
-        case CFG_128x128x32: L(128, 128, 32, AK, BKD); \
-        case CFG_128x64x32: L(128, 64, 32, AK, BKD); \
     }                                              \
     break;
 int launch_bf16_plain(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s) {

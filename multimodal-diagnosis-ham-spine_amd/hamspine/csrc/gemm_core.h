@@ -57,7 +57,6 @@ struct GemmArgs {
     int vec_store;             // 1: N%4==0 and all row strides/bases allow 4-wide accesses
     int seg_rows;              // >0: output rows are split over D / D_seg[0] / D_seg[1]
     char* D_seg[2];
-    int ablate;                // measurement builds only: 1 = no global loads after tile 0, 2 = no MFMA
 };
 
 // ------------------------------------------------------------------------------------------------

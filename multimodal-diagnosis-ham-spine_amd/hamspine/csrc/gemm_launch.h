@@ -2,7 +2,7 @@
 #pragma once
 #include "gemm_core.h"
 namespace hs {
-enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_STEM = 3, CFG_128x128x32 = 4, CFG_128x64x32 = 5 };
+enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_STEM = 3 };   // STEM: 128x64 tile with BK = 32
 // combos: 0 (KC,KC) 1 (KC,RC) 2 (RC,RC) 3 (CONV,KC) 4 (DGRAD,WDGRAD) 5 (RC,CONV)
 int launch_bf16_plain(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s);
 int launch_bf16_conv(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s);

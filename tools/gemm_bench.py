@@ -88,13 +88,13 @@ def conv_case(mode, N, Cin, H, Kout, R, stride):
 
 
 def deep():
-    """ablation ladder on one shape per tile config: bits 1 noload, 2 nomfma, 4 noepilogue, 8 nofragreads"""
+    """per tile config: default L2-grouped tile order vs plain n-fastest order (ablate bit 16)"""
     for kind, M, N, K in (("nt", 4096, 2304, 768), ("nt", 4096, 768, 3072), ("tn", 3072, 768, 4096)):
         fn = gemm_case(kind, M, N, K)
         fl = 2.0 * M * N * K
-        for cfg, nm in ((0, "128x128"), (1, "128x64"), (2, "64x64"), (4, "128x128x32"), (5, "128x64x32")):
+        for cfg, nm in ((0, "128x128"), (1, "128x64"), (2, "64x64")):
             out = []
-            for bits in (0, 1, 4, 13):
+            for bits in (0, 16):
                 lib.hs_gemm_debug(cfg, bits)
                 out.append((bits, timeit(fn) * 1e6))
             lib.hs_gemm_debug(-1, 0)
