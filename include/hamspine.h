@@ -106,11 +106,17 @@ typedef struct hs_gemm_params {
        rebased), rows below seg_rows to D.  Lets one GEMM write three parameter gradients (fused QKV wgrad). */
     int32_t seg_rows;
     void* D_seg[2];
+    /* optional (bf16 operands, no split-K, no batching): per (row tile, column) statistics of the result for a following
+       BatchNorm, written as (count, mean, M2) triples to colstats[(tile_row * N + n) * 3 ...]; hs_gemm_stat_rows(p) gives
+       the number of tile rows.  Saves BatchNorm's own pass over the convolution output (hs_bn_params.partial_rows). */
+    float* colstats;
 } hs_gemm_params;
 
 hs_status hs_gemm(const hs_gemm_params* p, void* stream);
 /* workspace (bytes) hs_gemm needs in p->splitk_ws for the given p (0 when split_k <= 1). */
 int64_t hs_gemm_splitk_ws_bytes(const hs_gemm_params* p);
+/* number of row tiles hs_gemm will use for p (rows of a colstats buffer); 0 when p cannot produce colstats. */
+int32_t hs_gemm_stat_rows(const hs_gemm_params* p);
 /* heuristic split-K factor for a (M,N,K) problem so that the grid fills 256 CUs. */
 int32_t hs_gemm_suggest_split(int32_t M, int32_t N, int32_t K, int32_t dtype);
 /* Optional timing of every GEMM-core launch with HIP events on its stream (measurement only).
@@ -154,6 +160,8 @@ typedef struct hs_bn_params {
     float* shift;            /* [C] out: beta - mean*gamma*invstd                                */
     void* ws;                /* hs_batchnorm_ws_bytes(M, C, dtype)                               */
     int64_t ws_bytes;
+    int32_t partial_rows;    /* > 0: ws already holds that many rows of (count, mean, M2) partials per channel
+                                (hs_gemm colstats): skip the statistics pass over x                */
 } hs_bn_params;
 
 typedef struct hs_bn_bwd_params {

@@ -51,7 +51,7 @@ class GemmParams(C.Structure):
         ("dropout_p", f32), ("dropout_seed", u64),
         ("mul_mode", i32), ("mul_src", vp), ("ldm", i32),
         ("accumulate", i32),
-        ("seg_rows", i32), ("D_seg", vp * 2),
+        ("seg_rows", i32), ("D_seg", vp * 2), ("colstats", vp),
     ]
 
 
@@ -61,7 +61,7 @@ class BnParams(C.Structure):
         ("eps", f32), ("momentum", f32),
         ("x", vp), ("residual", vp), ("y", vp), ("gamma", vp), ("beta", vp),
         ("running_mean", vp), ("running_var", vp), ("save_mean", vp), ("save_invstd", vp),
-        ("scale", vp), ("shift", vp), ("ws", vp), ("ws_bytes", i64),
+        ("scale", vp), ("shift", vp), ("ws", vp), ("ws_bytes", i64), ("partial_rows", i32),
     ]
 
 
@@ -145,6 +145,7 @@ def _declare(l):
     l.hs_gemm.argtypes = [P(GemmParams), vp]
     l.hs_gemm_splitk_ws_bytes.argtypes = [P(GemmParams)]
     l.hs_gemm_splitk_ws_bytes.restype = i64
+    l.hs_gemm_stat_rows.argtypes = [P(GemmParams)]
     l.hs_gemm_suggest_split.argtypes = [i32] * 4
     l.hs_batchnorm_fwd.argtypes = [P(BnParams), vp]
     l.hs_batchnorm_bwd.argtypes = [P(BnBwdParams), vp]

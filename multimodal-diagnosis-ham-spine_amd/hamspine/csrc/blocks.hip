@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void gather3_kernel(const float* __restrict__ 
 }
 
 int gemm_impl(const hs_gemm_params* p, hipStream_t stream);
+int gemm_stat_rows(const hs_gemm_params* p);
 
 static inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
 static inline int esize(int dt) { return dt == HS_BF16 ? 2 : 4; }
@@ -386,8 +387,19 @@ static hs_conv_geom geom_of(const ConvShape& s) {
     return g;
 }
 static bool is_pointwise(const ConvShape& s) { return s.R == 1 && s.stride == 1 && s.pad == 0; }
+static bool fused_bn_stats_enabled() {     // HAMSPINE_FUSED_BN_STATS=0: BatchNorm makes its own statistics pass
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("HAMSPINE_FUSED_BN_STATS");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
 
-static int conv_fwd_run(Run& r, const ConvShape& s, const void* x, const void* w_c, void* y) {
+// stats (optional, bf16 mode): receives the (count, mean, M2) partials of y per row tile for the BatchNorm that follows;
+// *stat_rows is set to the number of partial rows (0: not produced, BatchNorm makes its own pass)
+static int conv_fwd_run(Run& r, const ConvShape& s, const void* x, const void* w_c, void* y, float* stats = nullptr,
+                        int* stat_rows = nullptr) {
     hs_gemm_params p = gemm_defaults(r.dt);
     const long long Mo = (long long)s.N * s.P * s.Q;
     p.M = (int)Mo; p.N = s.Cout; p.K = s.R * s.R * s.Cin;
@@ -402,6 +414,14 @@ static int conv_fwd_run(Run& r, const ConvShape& s, const void* x, const void* w
         p.a_kind = HS_A_CONV; p.g = geom_of(s);
     }
     p.b_kind = HS_B_KC;
+    if (stat_rows) *stat_rows = 0;
+    if (stats && stat_rows && fused_bn_stats_enabled()) {
+        const int rows = gemm_stat_rows(&p);
+        if (rows > 0) {
+            p.colstats = stats;
+            *stat_rows = rows;
+        }
+    }
     CALL(r, gemm_impl(&p, r.s));
     return HS_OK;
 }
@@ -532,10 +552,11 @@ static int resblock_fwd_run(Run& r, const hs_resblock_desc& d, const void* x, vo
     const void* identity = x;
     if (d.has_ds) {
         const long long Mo = (long long)d.N * L.ds.s.P * L.ds.s.Q;
-        HS_PROPAGATE(conv_fwd_run(r, L.ds.s, x, L.ds.w_c, L.ds.c));
+        int srows = 0;
+        HS_PROPAGATE(conv_fwd_run(r, L.ds.s, x, L.ds.w_c, L.ds.c, d.training ? (float*)L.bn_ws : nullptr, &srows));
         hs_bn_params bp = bn_params(r, d, d.ds, L.ds, Mo);
         bp.y = L.ds.a; bp.relu = 0;
-        bp.ws = L.bn_ws; bp.ws_bytes = L.bn_ws_bytes;
+        bp.ws = L.bn_ws; bp.ws_bytes = L.bn_ws_bytes; bp.partial_rows = srows;
         CALL(r, hs_batchnorm_fwd(&bp, r.s));
         identity = L.ds.a;
     }
@@ -543,13 +564,14 @@ static int resblock_fwd_run(Run& r, const hs_resblock_desc& d, const void* x, vo
     for (int i = 0; i < d.n_main; ++i) {
         StageBuf& b = L.main[i];
         const long long Mo = (long long)d.N * b.s.P * b.s.Q;
-        HS_PROPAGATE(conv_fwd_run(r, b.s, in, b.w_c, b.c));
+        int srows = 0;
+        HS_PROPAGATE(conv_fwd_run(r, b.s, in, b.w_c, b.c, d.training ? (float*)L.bn_ws : nullptr, &srows));
         hs_bn_params bp = bn_params(r, d, d.main[i], b, Mo);
         const bool last = i + 1 == d.n_main;
         bp.y = last ? y : b.a;
         bp.relu = 1;
         bp.residual = last ? identity : nullptr;
-        bp.ws = L.bn_ws; bp.ws_bytes = L.bn_ws_bytes;
+        bp.ws = L.bn_ws; bp.ws_bytes = L.bn_ws_bytes; bp.partial_rows = srows;
         CALL(r, hs_batchnorm_fwd(&bp, r.s));
         in = b.a;
     }
@@ -699,10 +721,13 @@ static int stem_fwd_run(Run& r, const hs_stem_desc& d, const float* image, void*
     p.ldb = 224;
     p.g = L.g;
     p.D = L.c; p.ldd = cb.Cout;
+    int srows = 0;
+    if (d.training && fused_bn_stats_enabled() && (srows = gemm_stat_rows(&p)) > 0) p.colstats = (float*)L.bn_ws;
     CALL(r, gemm_impl(&p, r.s));
     hs_bn_params bp;
     memset(&bp, 0, sizeof(bp));
     bp.dtype = r.dt; bp.C = cb.Cout; bp.M = Mo;
+    bp.partial_rows = srows;
     bp.training = d.training; bp.relu = 1;
     bp.eps = d.eps; bp.momentum = d.momentum;
     bp.x = L.c; bp.y = L.a;

@@ -76,6 +76,22 @@ static int combo_of(int ak, int bk) {
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// tile choice for everything but the stem (see the comment at the call site)
+static int auto_cfg(const hs_gemm_params* p, bool vec) {
+    const long long z = (long long)(p->batch > 0 ? p->batch : 1) * (p->split_k > 1 ? p->split_k : 1);
+    const long long t12864 = (long long)ceil_div(p->M, 128) * ceil_div(p->N, 64) * z;
+    const long long t128 = (long long)ceil_div(p->M, 128) * ceil_div(p->N, 128) * z;
+    if (p->dtype == HS_BF16) return t12864 >= 1536 ? CFG_128x64 : CFG_64x64;
+    return (vec && t128 >= 200) ? CFG_128x128 : CFG_64x64;
+}
+// rows of a colstats buffer = row tiles the bf16 kernel will use for p
+int gemm_stat_rows(const hs_gemm_params* p) {
+    if (!p || p->dtype != HS_BF16 || p->split_k > 1 || p->batch > 1) return 0;
+    int cfg = (p->a_kind == HS_A_CONV && p->b_kind == HS_B_KC && p->g.C % 64 != 0) ? CFG_STEM : auto_cfg(p, true);
+    if (g_dbg_cfg >= 0 && g_dbg_cfg <= CFG_64x64 && cfg != CFG_STEM) cfg = g_dbg_cfg;
+    return ceil_div(p->M, cfg == CFG_64x64 ? 64 : 128);
+}
+
 int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     HS_REQUIRE(p != nullptr, "hs_gemm: null params");
     HS_REQUIRE(p->dtype == HS_F32 || p->dtype == HS_BF16, "hs_gemm: bad dtype %d", p->dtype);
@@ -128,6 +144,7 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     a.mul_src = (const char*)p->mul_src;
     a.ldm = p->ldm;
     a.accumulate = p->accumulate;
+    a.colstats = p->colstats;
     a.seg_rows = p->seg_rows;
     a.D_seg[0] = (char*)p->D_seg[0];
     a.D_seg[1] = (char*)p->D_seg[1];
@@ -202,13 +219,7 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     // tile selection.  Measured on MI355X (tools/gemm_bench.py, profiles/): the GEMMs of this workload are
     // 1-20 GFLOP, i.e. a few microseconds of MFMA time, so filling the chip evenly beats per-tile arithmetic
     // intensity: 128x128 never wins, 128x64 wins once it yields >= ~1500 tiles, otherwise 64x64.
-    if (cfg < 0) {
-        const long long z = (long long)batch * split;
-        const long long t12864 = (long long)ceil_div(p->M, 128) * ceil_div(p->N, 64) * z;
-        const long long t128 = (long long)ceil_div(p->M, 128) * ceil_div(p->N, 128) * z;
-        if (bf16) cfg = t12864 >= 1536 ? CFG_128x64 : CFG_64x64;
-        else cfg = (vec && t128 >= 200) ? CFG_128x128 : CFG_64x64;
-    }
+    if (cfg < 0) cfg = auto_cfg(p, vec);
     if (g_dbg_cfg >= 0 && g_dbg_cfg <= CFG_64x64 && cfg != CFG_STEM) cfg = g_dbg_cfg;
     int BM = 64, BN = 64;
     if (cfg == CFG_128x128) { BM = 128; BN = 128; }
@@ -240,6 +251,7 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
         a.k_per_split = ceil_div(ktiles, split) * kb_cfg;
         a.splitk_ws = p->splitk_ws;
     }
+    if (a.colstats) HS_REQUIRE(bf16 && split == 1 && batch == 1, "hs_gemm: colstats needs bf16 operands, no split-K, no batch");
     dim3 grid(a.tiles_m * a.tiles_n, 1, split > 1 ? split : batch);
     int st;
     ProfRec rec;
@@ -349,6 +361,7 @@ int hs_device_ok(void) {
     return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
 hs_status hs_gemm(const hs_gemm_params* p, void* stream) { return hs::gemm_impl(p, (hipStream_t)stream); }
+int32_t hs_gemm_stat_rows(const hs_gemm_params* p) { return hs::gemm_stat_rows(p); }
 int64_t hs_gemm_splitk_ws_bytes(const hs_gemm_params* p) {
     if (!p || p->split_k <= 1) return 0;
     return (int64_t)p->split_k * p->M * p->N * 4;

@@ -33,6 +33,7 @@ struct GemmArgs {
     long long a_bs0, a_bs1, b_bs0, b_bs1, d_bs0, d_bs1;   // in elements
     int tiles_m, tiles_n;
     int group_m;               // tile rows per L2 group (tile_from_block)
+    float* colstats;           // optional per (row tile, column) (count, mean, M2) of the result (fused BatchNorm statistics)
     int lds_stages;            // ring slots actually allocated: min(3, K tiles per workgroup) (bf16 kernel)
     int split_k;               // >1: blockIdx.z is the split index
     int k_per_split;           // multiple of BK
@@ -607,6 +608,54 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
                 for (int j = 0; j < FN; ++j) b0[j] = b1[j];
             }
             mma(a0, b0);
+        }
+    }
+
+    // ---- optional: column statistics of this tile for a following BatchNorm --------------------------
+    // Rows of the tile beyond M hold exact zeros (their operand rows were zero-filled), so plain sums over the whole
+    // tile with the true row count give the tile's (count, mean, M2).  Per column: in-lane sum over the FM row
+    // fragments, xor-shuffles over the 16 row lanes, then the two row waves fold through LDS (the ring is free now).
+    if (a.colstats) {
+        float s1[FN][4], s2[FN][4];
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float u = 0.f, w = 0.f;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const float v = acc[i][j][e] * a.alpha;
+                    u += v;
+                    w = fmaf(v, v, w);
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    u += __shfl_xor(u, o, 64);
+                    w += __shfl_xor(w, o, 64);
+                }
+                s1[j][e] = u;
+                s2[j][e] = w;
+            }
+        __syncthreads();                       // every wave is done with the last tile's fragments
+        float* sh = (float*)smem;              // [2 row waves][BN][2]
+        if (l15 == 0) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = wn * WN + j * 16 + 4 * g + e;
+                    sh[(wm * BN + c) * 2 + 0] = s1[j][e];
+                    sh[(wm * BN + c) * 2 + 1] = s2[j][e];
+                }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.N) {
+            const float t1 = sh[tid * 2] + sh[(BN + tid) * 2], t2 = sh[tid * 2 + 1] + sh[(BN + tid) * 2 + 1];
+            const float cnt = (float)min(BM, a.M - m0);
+            float* o = a.colstats + ((long long)tm * a.N + n0 + tid) * 3;
+            o[0] = cnt;
+            o[1] = t1 / cnt;
+            o[2] = fmaxf(t2 - t1 * t1 / cnt, 0.f);
         }
     }
 

@@ -379,11 +379,17 @@ static int bn_fwd_t(const hs_bn_params* p, hipStream_t s) {
     const int C = p->C;
     if (p->training) {
         ColGeom g = col_geom(M, C, E);
-        HS_REQUIRE(p->ws && p->ws_bytes >= (long long)g.gy * C * 3 * 4, "bn: workspace too small");
-        hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(g.gx, g.gy), dim3(256), 0, s, (const T*)p->x, M, C, g.tpc,
-                           (float*)p->ws);
-        HS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, (const float*)p->ws, g.gy, C, M,
+        int rows = g.gy;
+        if (p->partial_rows > 0) {     // the producing GEMM already left (count, mean, M2) per row tile in ws
+            rows = p->partial_rows;
+            HS_REQUIRE(p->ws && p->ws_bytes >= (long long)rows * C * 3 * 4, "bn: workspace smaller than the given partials");
+        } else {
+            HS_REQUIRE(p->ws && p->ws_bytes >= (long long)g.gy * C * 3 * 4, "bn: workspace too small");
+            hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(g.gx, g.gy), dim3(256), 0, s, (const T*)p->x, M, C, g.tpc,
+                               (float*)p->ws);
+            HS_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, (const float*)p->ws, rows, C, M,
                            p->eps, p->momentum, p->gamma, p->beta, p->running_mean, p->running_var, p->save_mean,
                            p->save_invstd, p->scale, p->shift);
         HS_LAUNCH_CHECK();
@@ -437,7 +443,10 @@ int bn_bwd(const hs_bn_bwd_params* p, hipStream_t s) {
 }
 long long bn_ws_bytes(long long M, int C, int dtype) {
     ColGeom g = col_geom(M, C, dtype == HS_BF16 ? 8 : 4);
-    return (long long)g.gy * C * 3 * 4 + 4ll * C * 4;   // partials (3 floats/channel/row block) + bwd coefficients
+    // partials (3 floats/channel/row block; up to one row per 64-row GEMM tile when the convolution supplies them) + bwd
+    // coefficients
+    const long long rows = std::max<long long>(g.gy, (M + 63) / 64);
+    return rows * C * 3 * 4 + 4ll * C * 4;
 }
 
 // ============================================================================================
