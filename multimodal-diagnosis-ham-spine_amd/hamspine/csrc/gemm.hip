@@ -371,7 +371,7 @@ int32_t hs_gemm_suggest_split(int32_t M, int32_t N, int32_t K, int32_t dtype) {
     const long long tiles = (long long)hs::ceil_div(M, 64) * hs::ceil_div(N, 64);
     const int ktiles = hs::ceil_div(K, bk);
     if (tiles >= 256 || ktiles < 16) return 1;
-    long long s = (512 + tiles - 1) / tiles;
+    long long s = (512 + tiles - 1) / tiles;   // 256/384/768 work units measured the same on C2 (16.3-16.4 ms/step)
     const long long smax = ktiles / 8 > 0 ? ktiles / 8 : 1;   // keep >= 8 k-tiles per split
     if (s > smax) s = smax;
     if (s > 64) s = 64;
