@@ -135,10 +135,10 @@ def patch_conv(x, weight, bias, k):
 
 
 class AttnCoreFn(Function):
-    """softmax(scale * q k^T) v on projected (B, L, heads*hd) tensors (no mask, no dropout)."""
+    """softmax(scale * q k^T [+ key mask]) v on projected (B, L, heads*hd) tensors (no dropout)."""
 
     @staticmethod
-    def _desc(q, k, heads, scale):
+    def _desc(q, k, heads, scale, key_mask=None, dropout_p=0.0, seed=0):
         B, Lq, D = q.shape
         d = L.AttnDesc()
         d.dtype = rt.hs_dtype(q)
@@ -146,41 +146,45 @@ class AttnCoreFn(Function):
         d.q_bs, d.k_bs, d.v_bs, d.o_bs = Lq * D, k.shape[1] * D, k.shape[1] * D, Lq * D
         d.q_ld, d.k_ld, d.v_ld, d.o_ld = D, D, D, D
         d.scale = scale
-        d.dropout_p = 0.0
-        d.seed = 0
-        d.key_mask = None
+        d.dropout_p = dropout_p
+        d.seed = seed
+        d.key_mask = rt.p(key_mask)
         return d
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, scale):
-        rt.need_gpu(q, k, v)
+    def forward(ctx, q, k, v, heads, scale, key_mask=None, dropout_p=0.0):
+        rt.need_gpu(q, k, v, key_mask)
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        d = AttnCoreFn._desc(q, k, heads, scale)
+        if key_mask is not None:
+            key_mask = key_mask.contiguous().long()
+        seed = rt.next_seed() if dropout_p > 0 else 0
+        d = AttnCoreFn._desc(q, k, heads, scale, key_mask, dropout_p, seed)
         sv_b, ws_b = rt.query(_lib().hs_attention_query, d)
         saved = torch.empty(sv_b, dtype=torch.uint8, device=q.device)
         ws = rt.workspace(ws_b, q.device)
         o = torch.empty_like(q)
         L.check(_lib().hs_attention_fwd(C.byref(d), rt.p(q), rt.p(k), rt.p(v), rt.p(o), rt.p(saved), sv_b, rt.p(ws),
                                         ws.numel(), rt.stream()), "hs_attention_fwd")
-        ctx.save_for_backward(q, k, v, saved)
-        ctx.meta = (heads, scale)
+        ctx.save_for_backward(q, k, v, saved, key_mask)
+        ctx.meta = (heads, scale, dropout_p, seed)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, saved = ctx.saved_tensors
-        heads, scale = ctx.meta
+        q, k, v, saved, key_mask = ctx.saved_tensors
+        heads, scale, dropout_p, seed = ctx.meta
         do = do.contiguous()
         if do.dtype != q.dtype:
             do = do.to(q.dtype)
-        d = AttnCoreFn._desc(q, k, heads, scale)
+        d = AttnCoreFn._desc(q, k, heads, scale, key_mask, dropout_p, seed)
         sv_b, ws_b = rt.query(_lib().hs_attention_query, d)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         ws = rt.workspace(ws_b, q.device)
         L.check(_lib().hs_attention_bwd(C.byref(d), rt.p(q), rt.p(k), rt.p(v), rt.p(do), rt.p(dq), rt.p(dk), rt.p(dv),
                                         rt.p(saved), saved.numel(), rt.p(ws), ws.numel(), rt.stream()), "hs_attention_bwd")
-        return dq, dk, dv, None, None
+        return dq, dk, dv, None, None, None, None
 
 
-def attention_core(q, k, v, heads=1, scale=1.0):
-    return AttnCoreFn.apply(q, k, v, heads, float(scale))
+def attention_core(q, k, v, heads=1, scale=1.0, key_mask=None, dropout_p=0.0):
+    """key_mask: optional (B, Lk) integer tensor, 0 = masked key; dropout_p: attention-probability dropout"""
+    return AttnCoreFn.apply(q, k, v, heads, float(scale), key_mask, float(dropout_p))

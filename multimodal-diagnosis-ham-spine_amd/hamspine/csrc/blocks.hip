@@ -21,6 +21,10 @@ __global__ __launch_bounds__(256) void gather3_kernel(const float* __restrict__ 
 
 int gemm_impl(const hs_gemm_params* p, hipStream_t stream);
 int gemm_stat_rows(const hs_gemm_params* p);
+int attention_bwd_fused(const hs_attn_desc& d, const void* q, const void* k, const void* v, const void* dO, void* dq, void* dk,
+                        void* dv, const void* P, int ldP, hipStream_t s);
+int attention_fwd_fused(const hs_attn_desc& d, const void* q, const void* k, const void* v, void* o, void* P, void* Pd, int ldP,
+                        hipStream_t s);
 
 static inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
 static inline int esize(int dt) { return dt == HS_BF16 ? 2 : 4; }
@@ -197,6 +201,18 @@ static int attention_fwd_run(Run& r, const hs_attn_desc& d, const void* q, const
     HS_PROPAGATE(attn_check(d));
     AttnLayout l = attn_layout(d, r, false);
     const int BH = d.B * d.H;
+    if (!r.plan && !r.saved.overflow && !r.ws.overflow) {
+        // BERT shape (bf16, head dim 64, <= 128 tokens): one fused kernel, scores stay in registers (csrc/attn_fused.hip)
+        const int fused = attention_fwd_fused(d, q, k, v, o, l.P, l.Pd, l.ldP, r.s);
+        if (fused < 0) {
+            set_error("attention_fwd: fused kernel launch failed");
+            return HS_ERR_HIP;
+        }
+        if (fused == 1) {
+            RUN_CHECK_ARENAS(r, "attention_fwd");
+            return HS_OK;
+        }
+    }
     // S = scale * Q K^T
     hs_gemm_params p = gemm_defaults(d.dtype);
     p.a_kind = HS_A_KC; p.b_kind = HS_B_KC;
@@ -239,6 +255,18 @@ static int attention_bwd_run(Run& r, const hs_attn_desc& d, const void* q, const
     const int BH = d.B * d.H;
     const long long o_el = span_elems(d.B, d.o_bs, d.Lq, d.o_ld, d.H, d.hd);
     const long long p_el = (long long)BH * d.Lq * l.ldP;
+    if (!r.plan && !r.saved.overflow && !r.ws.overflow) {
+        // BERT shape: one fused kernel (csrc/attn_fused.hip) instead of four batched GEMMs and the softmax backward
+        const int fused = attention_bwd_fused(d, q, k, v, dO, dq, dk, dv, l.P, l.ldP, r.s);
+        if (fused < 0) {
+            set_error("attention_bwd: fused kernel launch failed");
+            return HS_ERR_HIP;
+        }
+        if (fused == 1) {
+            RUN_CHECK_ARENAS(r, "attention_bwd");
+            return HS_OK;
+        }
+    }
     // dPd = dO V^T  (f32)
     hs_gemm_params p = gemm_defaults(d.dtype);
     p.a_kind = HS_A_KC; p.b_kind = HS_B_KC;

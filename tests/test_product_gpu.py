@@ -567,3 +567,59 @@ def test_full_size_c2_step_is_consistent_between_the_two_mfma_paths(tmp_path):
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("L,masked", [(128, False), (128, True), (96, True), (40, False)])
+def test_fused_attention_bert_shape_matches_reference(L, masked):
+    """bf16, head dim 64, <= 128 tokens takes the fused kernel (csrc/attn_fused.hip: scores in registers, P from the
+    accumulators straight into the P V product).  Reference: f32 torch attention on the same bf16-rounded q, k, v;
+    the backward (unfused GEMMs on the P the fused kernel saved) is checked through dq, dk, dv."""
+    from hamspine import convnext_ops as X
+    hamspine.set_compute_dtype("bf16")
+    B, H, hd = 3, 4, 64
+    g = torch.Generator().manual_seed(L)
+    q, k, v = (torch.randn(B, L, H * hd, generator=g).bfloat16() for _ in range(3))
+    cot = torch.randn(B, L, H * hd, generator=g).bfloat16().float()
+    mask = None
+    if masked:
+        mask = torch.ones(B, L, dtype=torch.long)
+        mask[0, L // 2:] = 0
+        mask[2, 5:] = 0
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+
+    def heads(t):
+        return t.view(B, L, H, hd).transpose(1, 2)
+    s = heads(qr) @ heads(kr).transpose(-1, -2) / 8.0
+    if mask is not None:
+        s = s.masked_fill(mask[:, None, None, :] == 0, -3.0e38)
+    ref = (torch.softmax(s, -1) @ heads(vr)).transpose(1, 2).reshape(B, L, H * hd)
+    (ref * cot).sum().backward()
+    qp, kp, vp = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    out = X.attention_core(qp, kp, vp, heads=H, scale=0.125, key_mask=None if mask is None else mask.to(DEV))
+    (out.float() * cot.to(DEV)).sum().backward()
+    _close(out, ref, "fused attention out", 2e-2)
+    _close(qp.grad, qr.grad, "dq", 3e-2)
+    _close(kp.grad, kr.grad, "dk", 3e-2)
+    _close(vp.grad, vr.grad, "dv", 3e-2)
+
+
+@pytest.mark.parametrize("hd", [64, 32])
+def test_attention_dropout_mask_is_the_same_in_forward_and_backward(hd):
+    """With V = 1 the output is the row sum of the dropped-out probabilities Pd, and with dO = 1 the gradient dV is its
+    column sum: both total sum(Pd), so forward and backward must have regenerated the same mask (hd 64 = fused kernels,
+    hd 32 = GEMM + softmax path).  The kept fraction is checked against 1 - p."""
+    from hamspine import convnext_ops as X
+    hamspine.set_compute_dtype("bf16")
+    B, H, L, p = 4, 4, 128, 0.25
+    g = torch.Generator().manual_seed(hd)
+    q, k = (torch.randn(B, L, H * hd, generator=g).bfloat16().to(DEV) for _ in range(2))
+    v = torch.ones(B, L, H * hd, dtype=torch.bfloat16, device=DEV).requires_grad_(True)
+    out = X.attention_core(q, k, v, heads=H, scale=hd ** -0.5, dropout_p=p)
+    out.float().sum().backward()
+    fwd_total = out.float()[:, :, ::hd].sum().item()          # one column per head: sum over rows of Pd
+    bwd_total = v.grad.float()[:, :, ::hd].sum().item()       # sum over columns of Pd
+    assert abs(fwd_total - bwd_total) <= 5e-3 * abs(fwd_total), (fwd_total, bwd_total)
+    # E[sum Pd] = number of rows; the realised total stays within a few percent at 2048 rows x 128 keys
+    assert abs(fwd_total / (B * H * L) - 1.0) < 0.05
+    o2 = X.attention_core(q, k, v.detach(), heads=H, scale=hd ** -0.5, dropout_p=p)
+    assert not torch.equal(o2, out.detach())                   # a new call draws a new mask
