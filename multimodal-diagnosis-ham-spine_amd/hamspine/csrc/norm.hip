@@ -454,7 +454,7 @@ long long bn_ws_bytes(long long M, int C, int dtype) {
 // ============================================================================================
 constexpr int LN_MAXV = 4;   // chunks per lane: H <= 64*8*4 = 2048 (bf16) / 1024 (f32)
 
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -464,10 +464,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int nch = H / E;
-    float v[LN_MAXV][E];
+    float v[NV][E];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
         if (c < nch) {
             Chunk<T>::unpack(*(const u32x4*)(x + row * H + (long long)c * E), v[i]);
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     const float mean = wave_sum(sum) / (float)H;
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
         if (c < nch) {
 #pragma unroll
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         if (rstd_out) rstd_out[row] = rstd;
     }
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
         if (c < nch) {
             float o[E];
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 
 // backward: each wave walks rows (stride = total waves), writes dx and keeps per-lane dgamma/dbeta
 // partials; the block's four waves merge theirs through LDS into ws[block][2][H]; a second kernel reduces over blocks.
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dx,
@@ -516,9 +516,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     const int nch = H / E;
-    float dg[LN_MAXV][E], db[LN_MAXV][E], gm[LN_MAXV][E];
+    float dg[NV][E], db[NV][E], gm[NV][E];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i)
+    for (int i = 0; i < NV; ++i)
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             dg[i][e] = db[i][e] = 0.f;
@@ -527,10 +527,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         }
     for (long long row = wid; row < M; row += nw) {
         const float mu = mean[row], rs = rstd[row];
-        float g[LN_MAXV][E], xh[LN_MAXV][E];
+        float g[NV][E], xh[NV][E];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
             if (c < nch) {
                 float xv[E];
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         s2 = wave_sum(s2) / (float)H;
         if (dx) {
 #pragma unroll
-            for (int i = 0; i < LN_MAXV; ++i) {
+            for (int i = 0; i < NV; ++i) {
                 const int c = lane + 64 * i;
                 if (c < nch) {
                     float o[E];
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int turn = 0; turn < 4; ++turn) {
         if (wv == turn) {
 #pragma unroll
-            for (int i = 0; i < LN_MAXV; ++i) {
+            for (int i = 0; i < NV; ++i) {
                 const int c = lane + 64 * i;
                 if (c < nch) {
 #pragma unroll
@@ -632,8 +632,14 @@ static int ln_fwd_t(const void* x, const float* gamma, const float* beta, void* 
                     long long M, int H, float eps, hipStream_t s) {
     constexpr int E = Chunk<T>::N;
     HS_REQUIRE(H % E == 0 && H <= 64 * E * LN_MAXV, "layernorm: H=%d unsupported for this dtype", H);
-    hipLaunchKernelGGL(ln_fwd_kernel<T>, dim3(ceil_div(M, 4)), dim3(256), 0, s, (const T*)x, gamma, beta, (T*)y, mean,
-                       rstd, M, H, eps);
+    // NV = 16-byte chunks per lane (registers scale with it: H = 768 in bf16 needs 2, not the maximum of 4)
+    const int nv = ceil_div(H / E, 64);
+#define LN_FWD(NVV) hipLaunchKernelGGL((ln_fwd_kernel<T, NVV>), dim3(ceil_div(M, 4)), dim3(256), 0, s, (const T*)x, gamma, beta, (T*)y, mean, rstd, M, H, eps)
+    if (nv <= 1) LN_FWD(1);
+    else if (nv == 2) LN_FWD(2);
+    else if (nv == 3) LN_FWD(3);
+    else LN_FWD(4);
+#undef LN_FWD
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
@@ -645,8 +651,13 @@ static int ln_bwd_t(const void* dy, const void* x, const float* gamma, const flo
     HS_REQUIRE(H % E == 0 && H <= 64 * E * LN_MAXV, "layernorm_bwd: H=%d unsupported for this dtype", H);
     const int blocks = ln_bwd_blocks(M);
     HS_REQUIRE(ws && ws_bytes >= (long long)blocks * 2 * H * 4, "layernorm_bwd: workspace too small");
-    hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3(blocks), dim3(256), 2 * H * sizeof(float), s, (const T*)dy, (const T*)x, gamma,
-                       mean, rstd, (T*)dx, ws, M, H);
+    const int nv = ceil_div(H / E, 64);
+#define LN_BWD(NVV) hipLaunchKernelGGL((ln_bwd_kernel<T, NVV>), dim3(blocks), dim3(256), 2 * H * sizeof(float), s, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, ws, M, H)
+    if (nv <= 1) LN_BWD(1);
+    else if (nv == 2) LN_BWD(2);
+    else if (nv == 3) LN_BWD(3);
+    else LN_BWD(4);
+#undef LN_BWD
     HS_LAUNCH_CHECK();
     hipLaunchKernelGGL(ln_bwd_final_kernel, dim3(ceil_div(H, 64)), dim3(256), 0, s, ws, blocks, H, dgamma, dbeta);
     HS_LAUNCH_CHECK();
