@@ -8,8 +8,8 @@ from hamspine.nn import Linear
 
 
 class SelfAttention(nn.Module):
-    """Spatial self-attention over a (B, C, H, W) map (reference attention.py:5-22).  MIBF-Net builds one
-    (`I2Iattention`, model_resnet.py:21) and never calls it; the parameters exist for checkpoint fidelity."""
+    """Spatial self-attention over a (B, C, H, W) map (reference attention.py:5-22): softmax(Q K^T / sqrt(C)) V over the
+    H*W positions.  MIBF-Net builds one (`I2Iattention`, model_resnet.py:21) and never calls it."""
 
     def __init__(self, input_dim):
         super().__init__()
@@ -19,7 +19,12 @@ class SelfAttention(nn.Module):
         self.softmax = nn.Softmax(dim=-1)
 
     def forward(self, x):
-        raise NotImplementedError("SelfAttention is constructed but never evaluated by the reference model")
+        b, c, hh, ww = x.shape
+        tokens = x.permute(0, 2, 3, 1).reshape(b, hh * ww, c)        # (B, HW, C); free for channels_last memory
+        if not tokens.is_contiguous():
+            tokens = tokens.contiguous()
+        out = X.attention_core(self.query(tokens), self.key(tokens), self.value(tokens), heads=1, scale=1.0 / (c ** 0.5))
+        return out.reshape(b, hh, ww, c).permute(0, 3, 1, 2)         # (B, C, H, W), channels_last memory
 
 
 def compute_kl_divergence(p, q, eps=1e-8):

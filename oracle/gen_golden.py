@@ -139,6 +139,7 @@ def gen_ibfa():
     x, y = rnd((B, 1, D), 41), rnd((B, 1, D), 42)
     run_case("ibfa_h1", att.MultiHeadCrossAttention_v2(D, 1), dict(x=x, y=y), SEED + 60)
     run_case("ibfa_h4", att.MultiHeadCrossAttention_v2(D, 4), dict(x=x, y=y), SEED + 61)
+    run_case("ibfa_selfattention", att.SelfAttention(D), dict(x=rnd((3, D, 5, 4), 47)), SEED + 63)
     run_case("ibfa_tokens", att.MultiHeadCrossAttention_v2(D, 4), dict(x=rnd((B, 3, D), 45), y=rnd((B, 6, D), 46)), SEED + 62)
     p = torch.softmax(rnd((B, 6), 43), -1)
     q = torch.softmax(rnd((B, 6), 44), -1)

@@ -82,6 +82,7 @@ MODULE_CASES = {
                 call_kwargs),
     "ibfa_h1": (SEED + 60, lambda: _o().OCrossAttnV2(64, 1), lambda: _p()[4].MultiHeadCrossAttention_v2(64, 1), call_kwargs),
     "ibfa_h4": (SEED + 61, lambda: _o().OCrossAttnV2(64, 4), lambda: _p()[4].MultiHeadCrossAttention_v2(64, 4), call_kwargs),
+    "ibfa_selfattention": (SEED + 63, lambda: _o().OSelfAttention(64), lambda: _p()[4].SelfAttention(64), call_kwargs),
     "ibfa_tokens": (SEED + 62, lambda: _o().OCrossAttnV2(64, 4), lambda: _p()[4].MultiHeadCrossAttention_v2(64, 4), call_kwargs),
 }
 
