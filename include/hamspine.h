@@ -195,6 +195,13 @@ hs_status hs_layernorm_fwd(int32_t dtype, const void* x, const float* gamma, con
 hs_status hs_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* gamma, const float* mean,
                            const float* rstd, void* dx, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes,
                            int64_t M, int32_t H, void* stream);
+/* the same, also serving the layer in front of the LayerNorm (BertSelfOutput / BertOutput: y = LN(dropout(dense(h)) + x)):
+   dx_dropped = dx * dropout mask (same (seed, element index) mask as the forward; p = 0: a copy; may be NULL) and
+   dbias[H] = column sums of dx_dropped = that dense layer's bias gradient.  Saves the stand-alone dropout and column-sum
+   passes of transformers BertSelfOutput / BertOutput backward. */
+hs_status hs_layernorm_bwd_pre(int32_t dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                               const float* rstd, void* dx, float* dgamma, float* dbeta, void* dx_dropped, float* dbias,
+                               float dropout_p, uint64_t seed, void* ws, int64_t ws_bytes, int64_t M, int32_t H, void* stream);
 int64_t hs_layernorm_bwd_ws_bytes(int64_t M, int32_t H);
 
 /* ------------------------------------------------------------------------------------------- */

@@ -153,6 +153,7 @@ def _declare(l):
     l.hs_batchnorm_ws_bytes.restype = i64
     l.hs_layernorm_fwd.argtypes = [i32, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp]
     l.hs_layernorm_bwd.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, vp]
+    l.hs_layernorm_bwd_pre.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, u64, vp, i64, i64, i32, vp]
     l.hs_layernorm_bwd_ws_bytes.argtypes = [i64, i32]
     l.hs_layernorm_bwd_ws_bytes.restype = i64
     l.hs_maxpool_fwd.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]

@@ -415,6 +415,14 @@ static hs_conv_geom geom_of(const ConvShape& s) {
     return g;
 }
 static bool is_pointwise(const ConvShape& s) { return s.R == 1 && s.stride == 1 && s.pad == 0; }
+static bool fused_ln_bwd_enabled() {        // HAMSPINE_FUSED_LN_BWD=0: separate LayerNorm-backward / dropout / column-sum passes
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("HAMSPINE_FUSED_LN_BWD");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
 static bool fused_bn_stats_enabled() {     // HAMSPINE_FUSED_BN_STATS=0: BatchNorm makes its own statistics pass
     static int v = -1;
     if (v < 0) {
@@ -934,27 +942,41 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
     HS_PROPAGATE(side_setup(r));
 
     // ---- output LN + FFN ----
-    CALL(r, hs_layernorm_bwd(r.dt, dy, L.h2, d.ln2.gamma, L.mean2, L.rstd2, dh2, d.ln2.dgamma ? d.ln2.dgamma : scratch,
-                             d.ln2.dbeta ? d.ln2.dbeta : (scratch ? scratch + Hd : nullptr), ln_ws, ln_ws_bytes, M, Hd, r.s));
-    const void* g2 = dh2;
-    if (d.hidden_dropout > 0.f) {
-        CALL(r, hs_dropout(r.dt, dh2, dd2, M * Hd, d.hidden_dropout, d.seed * 8 + 3, r.s));
-        g2 = dd2;
+    // one pass: LayerNorm backward, the hidden-dropout mask of the dense output and that dense layer's bias gradient
+    const bool fuse_ln = fused_ln_bwd_enabled();
+    const void* g2 = d.hidden_dropout > 0.f ? dd2 : dh2;
+    hs_linear out_l_w = d.out_l;
+    if (fuse_ln) {
+        CALL(r, hs_layernorm_bwd_pre(r.dt, dy, L.h2, d.ln2.gamma, L.mean2, L.rstd2, dh2, d.ln2.dgamma ? d.ln2.dgamma : scratch,
+                                     d.ln2.dbeta ? d.ln2.dbeta : (scratch ? scratch + Hd : nullptr),
+                                     d.hidden_dropout > 0.f ? dd2 : nullptr, d.out_l.db, d.hidden_dropout, d.seed * 8 + 3,
+                                     ln_ws, ln_ws_bytes, M, Hd, r.s));
+        out_l_w.db = nullptr;                  // bias gradient already produced above
+    } else {
+        CALL(r, hs_layernorm_bwd(r.dt, dy, L.h2, d.ln2.gamma, L.mean2, L.rstd2, dh2, d.ln2.dgamma ? d.ln2.dgamma : scratch,
+                                 d.ln2.dbeta ? d.ln2.dbeta : (scratch ? scratch + Hd : nullptr), ln_ws, ln_ws_bytes, M, Hd, r.s));
+        if (d.hidden_dropout > 0.f) CALL(r, hs_dropout(r.dt, dh2, dd2, M * Hd, d.hidden_dropout, d.seed * 8 + 3, r.s));
     }
-    HS_PROPAGATE(on_side(r, [&]() { return linear_wgrad_run(r, L.g, M, I, d.out_l, g2, Hd); }));
+    HS_PROPAGATE(on_side(r, [&]() { return linear_wgrad_run(r, L.g, M, I, out_l_w, g2, Hd); }));
     HS_PROPAGATE(linear_dgrad_run(r, d.out_l, L.wo, g2, M, Hd, du, I, r.dt, HS_MUL_GELU_GRAD, L.u, I, nullptr));
     HS_PROPAGATE(on_side(r, [&]() { return linear_wgrad_run(r, L.x1, M, Hd, d.inter_l, du, I); }));
     // dx1 = du Wi + dh2 (residual into x1)
     HS_PROPAGATE(linear_dgrad_run(r, d.inter_l, L.wi, du, M, I, dx1, Hd, r.dt, HS_MUL_NONE, nullptr, 0, dh2));
     // ---- attention output LN + dense ----
-    CALL(r, hs_layernorm_bwd(r.dt, dx1, L.h1, d.ln1.gamma, L.mean1, L.rstd1, dh1, d.ln1.dgamma ? d.ln1.dgamma : scratch,
-                             d.ln1.dbeta ? d.ln1.dbeta : (scratch ? scratch + Hd : nullptr), ln_ws, ln_ws_bytes, M, Hd, r.s));
-    const void* g1 = dh1;
-    if (d.hidden_dropout > 0.f) {
-        CALL(r, hs_dropout(r.dt, dh1, dd1, M * Hd, d.hidden_dropout, d.seed * 8 + 2, r.s));
-        g1 = dd1;
+    const void* g1 = d.hidden_dropout > 0.f ? dd1 : dh1;
+    hs_linear ao_w = d.ao;
+    if (fuse_ln) {
+        CALL(r, hs_layernorm_bwd_pre(r.dt, dx1, L.h1, d.ln1.gamma, L.mean1, L.rstd1, dh1, d.ln1.dgamma ? d.ln1.dgamma : scratch,
+                                     d.ln1.dbeta ? d.ln1.dbeta : (scratch ? scratch + Hd : nullptr),
+                                     d.hidden_dropout > 0.f ? dd1 : nullptr, d.ao.db, d.hidden_dropout, d.seed * 8 + 2,
+                                     ln_ws, ln_ws_bytes, M, Hd, r.s));
+        ao_w.db = nullptr;
+    } else {
+        CALL(r, hs_layernorm_bwd(r.dt, dx1, L.h1, d.ln1.gamma, L.mean1, L.rstd1, dh1, d.ln1.dgamma ? d.ln1.dgamma : scratch,
+                                 d.ln1.dbeta ? d.ln1.dbeta : (scratch ? scratch + Hd : nullptr), ln_ws, ln_ws_bytes, M, Hd, r.s));
+        if (d.hidden_dropout > 0.f) CALL(r, hs_dropout(r.dt, dh1, dd1, M * Hd, d.hidden_dropout, d.seed * 8 + 2, r.s));
     }
-    HS_PROPAGATE(on_side(r, [&]() { return linear_wgrad_run(r, L.ctx, M, Hd, d.ao, g1, Hd); }));
+    HS_PROPAGATE(on_side(r, [&]() { return linear_wgrad_run(r, L.ctx, M, Hd, ao_w, g1, Hd); }));
     HS_PROPAGATE(linear_dgrad_run(r, d.ao, L.wao, g1, M, Hd, dctx, Hd, r.dt, HS_MUL_NONE, nullptr, 0, nullptr));
     // ---- attention core ----
     const char* qkv = (const char*)L.qkv;

@@ -507,12 +507,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 
 // backward: each wave walks rows (stride = total waves), writes dx and keeps per-lane dgamma/dbeta
 // partials; the block's four waves merge theirs through LDS into ws[block][2][H]; a second kernel reduces over blocks.
-template <typename T, int NV>
+// PRE (compile time): also emit what the layer in front of this LayerNorm needs -- dxd = dx * dropout mask (the forward
+// applied dropout to that layer's output before the residual add) and the column sums of dxd (its bias gradient), as
+// a third partial row.
+template <typename T, int NV, bool PRE>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dx,
-                                                     float* __restrict__ ws, long long M, int H) {
+                                                     float* __restrict__ ws, long long M, int H, T* __restrict__ dxd,
+                                                     unsigned thresh, float inv_keep, unsigned long long seed) {
     constexpr int E = Chunk<T>::N;
+    constexpr int NP = PRE ? 3 : 2;          // partial rows per block: dgamma, dbeta (, bias gradient)
+    float dbs[PRE ? NV : 1][E];
+#pragma unroll
+    for (int i = 0; i < (PRE ? NV : 1); ++i)
+#pragma unroll
+        for (int e = 0; e < E; ++e) dbs[i][e] = 0.f;
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     const int nch = H / E;
@@ -549,7 +559,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         }
         s1 = wave_sum(s1) / (float)H;
         s2 = wave_sum(s2) / (float)H;
-        if (dx) {
+        if (dx || PRE) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int c = lane + 64 * i;
@@ -557,13 +567,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                     float o[E];
 #pragma unroll
                     for (int e = 0; e < E; ++e) o[e] = rs * (g[i][e] * gm[i][e] - s1 - xh[i][e] * s2);
-                    *(u32x4*)(dx + row * H + (long long)c * E) = Chunk<T>::pack(o);
+                    if (dx) *(u32x4*)(dx + row * H + (long long)c * E) = Chunk<T>::pack(o);
+                    if constexpr (PRE) {
+                        if (thresh) {
+#pragma unroll
+                            for (int q4 = 0; q4 < E / 4; ++q4) {
+                                float sc[4];
+                                dropout_scale4(seed, (unsigned long long)row * H + (unsigned long long)c * E + 4 * q4, thresh, inv_keep, sc);
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) o[4 * q4 + k] *= sc[k];
+                            }
+                        }
+                        if (dxd) *(u32x4*)(dxd + row * H + (long long)c * E) = Chunk<T>::pack(o);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) dbs[i][e] += o[e];
+                    }
                 }
             }
         }
     }
     // merge the four waves of the block in a fixed order through LDS, then one partial row per block
-    extern __shared__ float ln_sh[];   // [2][H]
+    extern __shared__ float ln_sh[];   // [NP][H]
     const int wv = threadIdx.x >> 6;
     for (int turn = 0; turn < 4; ++turn) {
         if (wv == turn) {
@@ -577,9 +601,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                         if (turn == 0) {
                             ln_sh[k] = dg[i][e];
                             ln_sh[H + k] = db[i][e];
+                            if constexpr (PRE) ln_sh[2 * H + k] = dbs[i][e];
                         } else {
                             ln_sh[k] += dg[i][e];
                             ln_sh[H + k] += db[i][e];
+                            if constexpr (PRE) ln_sh[2 * H + k] += dbs[i][e];
                         }
                     }
                 }
@@ -587,36 +613,41 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         }
         __syncthreads();
     }
-    for (int k = threadIdx.x; k < 2 * H; k += 256) ws[(long long)blockIdx.x * 2 * H + k] = ln_sh[k];
+    for (int k = threadIdx.x; k < NP * H; k += 256) ws[(long long)blockIdx.x * NP * H + k] = ln_sh[k];
 }
-__global__ __launch_bounds__(256) void ln_bwd_final_kernel(const float* __restrict__ ws, int nw, int H,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    // block = 64 columns x 4 row groups: coalesced 256-byte row segments, 4 partial sums merged through LDS
-    __shared__ float sa[4][64], sb[4][64];
+__global__ __launch_bounds__(256) void ln_bwd_final_kernel(const float* __restrict__ ws, int nw, int H, int np,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ dbias) {
+    // block = 64 columns x 4 row groups: coalesced 256-byte row segments, 4 partial sums merged through LDS;
+    // partial row w holds np (2 or 3) vectors of H floats: dgamma, dbeta(, bias gradient of the preceding layer)
+    __shared__ float sh[3][4][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
-    float a = 0.f, b = 0.f;
+    float acc[3] = {0.f, 0.f, 0.f};
     if (c < H) {
         int w = rg;
         for (; w + 12 < nw; w += 16) {   // 4 independent loads in flight per accumulator
-            const float a0 = ws[((long long)w * 2 + 0) * H + c], a1 = ws[((long long)(w + 4) * 2 + 0) * H + c];
-            const float a2 = ws[((long long)(w + 8) * 2 + 0) * H + c], a3 = ws[((long long)(w + 12) * 2 + 0) * H + c];
-            const float b0 = ws[((long long)w * 2 + 1) * H + c], b1 = ws[((long long)(w + 4) * 2 + 1) * H + c];
-            const float b2 = ws[((long long)(w + 8) * 2 + 1) * H + c], b3 = ws[((long long)(w + 12) * 2 + 1) * H + c];
-            a += (a0 + a1) + (a2 + a3);
-            b += (b0 + b1) + (b2 + b3);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k < np) {
+                    const float v0 = ws[((long long)w * np + k) * H + c], v1 = ws[((long long)(w + 4) * np + k) * H + c];
+                    const float v2 = ws[((long long)(w + 8) * np + k) * H + c], v3 = ws[((long long)(w + 12) * np + k) * H + c];
+                    acc[k] += (v0 + v1) + (v2 + v3);
+                }
+            }
         }
-        for (; w < nw; w += 4) {
-            a += ws[((long long)w * 2 + 0) * H + c];
-            b += ws[((long long)w * 2 + 1) * H + c];
-        }
+        for (; w < nw; w += 4)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k < np) acc[k] += ws[((long long)w * np + k) * H + c];
     }
-    sa[rg][cl] = a;
-    sb[rg][cl] = b;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sh[k][rg][cl] = acc[k];
     __syncthreads();
     if (rg == 0 && c < H) {
-        dgamma[c] = (sa[0][cl] + sa[1][cl]) + (sa[2][cl] + sa[3][cl]);
-        dbeta[c] = (sb[0][cl] + sb[1][cl]) + (sb[2][cl] + sb[3][cl]);
+        dgamma[c] = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
+        dbeta[c] = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
+        if (np > 2 && dbias) dbias[c] = (sh[2][0][cl] + sh[2][1][cl]) + (sh[2][2][cl] + sh[2][3][cl]);
     }
 }
 
@@ -646,20 +677,33 @@ static int ln_fwd_t(const void* x, const float* gamma, const float* beta, void* 
 template <typename T>
 static int ln_bwd_t(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                     void* dx, float* dgamma, float* dbeta, float* ws, long long ws_bytes, long long M, int H,
-                    hipStream_t s) {
+                    hipStream_t s, bool pre = false, void* dxd = nullptr, float* dbias = nullptr, float p = 0.f,
+                    unsigned long long seed = 0) {
     constexpr int E = Chunk<T>::N;
     HS_REQUIRE(H % E == 0 && H <= 64 * E * LN_MAXV, "layernorm_bwd: H=%d unsupported for this dtype", H);
     const int blocks = ln_bwd_blocks(M);
-    HS_REQUIRE(ws && ws_bytes >= (long long)blocks * 2 * H * 4, "layernorm_bwd: workspace too small");
+    const int np = pre ? 3 : 2;
+    HS_REQUIRE(ws && ws_bytes >= (long long)blocks * np * H * 4, "layernorm_bwd: workspace too small");
     const int nv = ceil_div(H / E, 64);
-#define LN_BWD(NVV) hipLaunchKernelGGL((ln_bwd_kernel<T, NVV>), dim3(blocks), dim3(256), 2 * H * sizeof(float), s, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, ws, M, H)
-    if (nv <= 1) LN_BWD(1);
-    else if (nv == 2) LN_BWD(2);
-    else if (nv == 3) LN_BWD(3);
-    else LN_BWD(4);
+    const unsigned th = (pre && p > 0.f) ? dropout_thresh(p) : 0u;
+    const float ik = (pre && p > 0.f) ? 1.f / (1.f - p) : 1.f;
+#define LN_BWD(NVV, PRE)                                                                                                  \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, NVV, PRE>), dim3(blocks), dim3(256), np * H * sizeof(float), s, (const T*)dy,     \
+                       (const T*)x, gamma, mean, rstd, (T*)dx, ws, M, H, (T*)dxd, th, ik, seed)
+    if (pre) {
+        if (nv <= 1) LN_BWD(1, true);
+        else if (nv == 2) LN_BWD(2, true);
+        else if (nv == 3) LN_BWD(3, true);
+        else LN_BWD(4, true);
+    } else {
+        if (nv <= 1) LN_BWD(1, false);
+        else if (nv == 2) LN_BWD(2, false);
+        else if (nv == 3) LN_BWD(3, false);
+        else LN_BWD(4, false);
+    }
 #undef LN_BWD
     HS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3(ceil_div(H, 64)), dim3(256), 0, s, ws, blocks, H, dgamma, dbeta);
+    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3(ceil_div(H, 64)), dim3(256), 0, s, ws, blocks, H, np, dgamma, dbeta, dbias);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
@@ -676,7 +720,18 @@ int ln_bwd(int dtype, const void* dy, const void* x, const float* gamma, const f
     return dtype == HS_BF16 ? ln_bwd_t<bf16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, ws_bytes, M, H, s)
                             : ln_bwd_t<float>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, ws_bytes, M, H, s);
 }
-long long ln_bwd_ws_bytes(long long M, int H) { return (long long)ln_bwd_blocks(M) * 2 * H * 4; }
+// LayerNorm backward that also serves the layer in front of it: dx_dropped = dx * dropout mask(p, seed, element index)
+// (p = 0: dx itself; may be NULL) and dbias = column sums of dx_dropped.
+int ln_bwd_pre(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+               float* dgamma, float* dbeta, void* dx_dropped, float* dbias, float p, unsigned long long seed, float* ws,
+               long long ws_bytes, long long M, int H, hipStream_t s) {
+    HS_REQUIRE(dy && x && gamma && mean && rstd && dgamma && dbeta, "layernorm_bwd_pre: null argument");
+    HS_REQUIRE(p >= 0.f && p < 1.f, "layernorm_bwd_pre: bad dropout probability");
+    return dtype == HS_BF16
+               ? ln_bwd_t<bf16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, ws_bytes, M, H, s, true, dx_dropped, dbias, p, seed)
+               : ln_bwd_t<float>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, ws_bytes, M, H, s, true, dx_dropped, dbias, p, seed);
+}
+long long ln_bwd_ws_bytes(long long M, int H) { return (long long)ln_bwd_blocks(M) * 3 * H * 4; }
 
 }  // namespace hs
 
@@ -693,6 +748,12 @@ hs_status hs_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const f
                            int64_t M, int32_t H, void* stream) {
     return hs::ln_bwd(dtype, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, (float*)ws, ws_bytes, M, H,
                       (hipStream_t)stream);
+}
+hs_status hs_layernorm_bwd_pre(int32_t dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                               const float* rstd, void* dx, float* dgamma, float* dbeta, void* dx_dropped, float* dbias,
+                               float dropout_p, uint64_t seed, void* ws, int64_t ws_bytes, int64_t M, int32_t H, void* stream) {
+    return hs::ln_bwd_pre(dtype, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dx_dropped, dbias, dropout_p, seed, (float*)ws,
+                          ws_bytes, M, H, (hipStream_t)stream);
 }
 int64_t hs_layernorm_bwd_ws_bytes(int64_t M, int32_t H) { return hs::ln_bwd_ws_bytes(M, H); }
 }

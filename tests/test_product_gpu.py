@@ -623,3 +623,47 @@ def test_attention_dropout_mask_is_the_same_in_forward_and_backward(hd):
     assert abs(fwd_total / (B * H * L) - 1.0) < 0.05
     o2 = X.attention_core(q, k, v.detach(), heads=H, scale=hd ** -0.5, dropout_p=p)
     assert not torch.equal(o2, out.detach())                   # a new call draws a new mask
+
+
+def test_bert_dropout_forward_and_backward_share_their_masks():
+    """Train-mode BERT with hidden AND attention dropout in exact-f32 mode: with the seed counter reset before every
+    evaluation the masks repeat, so f is a fixed smooth function and the analytic directional derivative <grad, v> must
+    match central differences.  A mask regenerated differently in any backward kernel (GEMM epilogues, the fused
+    LayerNorm-backward/dropout/bias pass, softmax backward) breaks this by O(p)."""
+    from hamspine import rt
+    from hamspine.nn import BertConfig, BertModel
+    cfg = BertConfig(vocab_size=100, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                     max_position_embeddings=32, hidden_dropout_prob=0.25, attention_probs_dropout_prob=0.2)
+    m = load_procedural(BertModel(cfg), 3).to(DEV).train()
+    ids = torch.randint(1, 100, (3, 24), generator=torch.Generator().manual_seed(1)).to(DEV)
+    mask = torch.ones(3, 24, dtype=torch.long, device=DEV)
+    mask[1, 15:] = 0
+    cot = torch.randn(3, 24, 64, generator=torch.Generator().manual_seed(2)).to(DEV)
+    names = ["encoder.layer.0.output.dense.bias", "encoder.layer.1.attention.output.dense.weight",
+             "encoder.layer.0.intermediate.dense.weight", "encoder.layer.1.attention.self.value.weight",
+             "encoder.layer.0.attention.output.LayerNorm.weight", "embeddings.position_embeddings.weight"]
+    params = dict(m.named_parameters())
+
+    def f():
+        rt.reset_seed(1234)
+        return (m(input_ids=ids, attention_mask=mask).last_hidden_state * cot).sum()
+
+    base = f()
+    base.backward()
+    again = f()
+    assert torch.equal(base.detach(), again.detach())              # same seeds -> same masks -> same value
+    for k in names:
+        p = params[k]
+        v = torch.randn(p.shape, generator=torch.Generator().manual_seed(7)).to(DEV)
+        v /= v.norm()
+        analytic = (p.grad * v).sum().item()
+        eps = 2e-2
+        with torch.no_grad():
+            p.add_(eps * v)
+            up = f().item()
+            p.add_(-2 * eps * v)
+            dn = f().item()
+            p.add_(eps * v)
+        numeric = (up - dn) / (2 * eps)
+        assert abs(numeric - analytic) <= 3e-2 * max(abs(analytic), abs(numeric)) + 2e-3, (k, analytic, numeric)
+    rt.reset_seed(None)
