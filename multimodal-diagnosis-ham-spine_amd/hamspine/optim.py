@@ -91,33 +91,54 @@ class _FusedAdamBase(torch.optim.Optimizer):
         if not ps:
             return
         lib = L.lib()
-        rt.need_gpu(*ps)
-        steps = set()
-        for p in ps:
-            st = self.state[p]
-            if not st:
-                st["step"] = 0
-                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            st["step"] = int(st["step"]) + 1
-            steps.add(st["step"])
-        b1, b2 = group["betas"]
-        for step in steps:          # tensors of a group normally share the step count (they are created together)
-            sel = [p for p in ps if self.state[p]["step"] == step]
-            n = len(sel)
-            for p in sel:
-                if p.dtype != torch.float32 or p.grad.dtype != torch.float32:
+        # pointer tables of everything that does not move between steps (parameters, both moments, sizes) are built once
+        # per parameter set; only the gradient table is rebuilt (gradients are fresh tensors every step)
+        key = (id(group), len(ps), id(ps[0]), id(ps[-1]))
+        cache = self.__dict__.setdefault("_tables", {})
+        ent = cache.get(key)
+        if ent is None or ent["ps"] != [id(p) for p in ps]:
+            rt.need_gpu(*ps)
+            for p in ps:
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if p.dtype != torch.float32:
                     raise L.HamspineError("FusedAdam expects f32 parameters and gradients")
-                # elementwise update: any dense layout works as long as p / grad / state share it
-                if p.grad.stride() != p.stride():
+            by_step = {}
+            for p in ps:
+                by_step.setdefault(int(self.state[p]["step"]), []).append(p)
+            ent = {"ps": [id(p) for p in ps], "chunks": []}
+            for step0, sel in by_step.items():      # tensors of a group normally share the step count
+                n = len(sel)
+                arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+                ent["chunks"].append({
+                    "sel": sel, "n": n, "p": arr(sel), "m": arr([self.state[p]["exp_avg"] for p in sel]),
+                    "v": arr([self.state[p]["exp_avg_sq"] for p in sel]), "cnt": (C.c_int64 * n)(*[p.numel() for p in sel]),
+                    "ptrs": [p.data_ptr() for p in sel], "strides": [p.stride() for p in sel]})
+            cache[key] = ent
+        b1, b2 = group["betas"]
+        for ch in ent["chunks"]:
+            sel, n = ch["sel"], ch["n"]
+            if any(p.data_ptr() != q for p, q in zip(sel, ch["ptrs"])):     # a parameter was re-allocated (.to(), load)
+                cache.pop(key, None)
+                return self._update(group, ps, grad_scale)
+            grads = []
+            for p, st in zip(sel, ch["strides"]):
+                g = p.grad
+                if g.dtype != torch.float32:
+                    raise L.HamspineError("FusedAdam expects f32 parameters and gradients")
+                if g.stride() != st:    # rare: a gradient produced outside our nodes in another layout
                     g2 = torch.empty_like(p, memory_format=torch.preserve_format)
-                    g2.copy_(p.grad)   # rare: a gradient produced outside our nodes in another layout
-                    p.grad = g2
-            arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
-            cnt = (C.c_int64 * n)(*[p.numel() for p in sel])
+                    g2.copy_(g)
+                    p.grad = g = g2
+                grads.append(g.data_ptr())
+            step = int(self.state[sel[0]]["step"]) + 1
+            for p in sel:
+                self.state[p]["step"] = step
             L.check(lib.hs_adam_step_multi(
-                n, arr(sel), arr([p.grad for p in sel]), arr([self.state[p]["exp_avg"] for p in sel]),
-                arr([self.state[p]["exp_avg_sq"] for p in sel]), cnt, float(group["lr"]), b1, b2, group["eps"],
+                n, ch["p"], (C.c_void_p * n)(*grads), ch["m"], ch["v"], ch["cnt"], float(group["lr"]), b1, b2, group["eps"],
                 group["weight_decay"], step, 1 if self._decoupled else 0, float(grad_scale), rt.stream()),
                 "hs_adam_step_multi")
 
