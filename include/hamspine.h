@@ -329,6 +329,12 @@ hs_status hs_gru_cell_fwd(const float* gx, int32_t ldx, const float* gh, int32_t
 hs_status hs_gru_cell_bwd(const float* dh, const float* act, const float* h_prev, float* dgx, float* dgh, float* dh_prev,
                           int32_t B, int32_t H, void* stream);
 
+/* KANLinear.regularization_loss (reference ConNexT/models/block/kan1.py:216-236) on spline_weight viewed as
+   [rows = out*in][coeffs]: loss = ra * sum_j l_j + re * entropy(l / sum l), l_j = mean_c |w[j][c]|; dw (optional) is
+   d loss / d w.  Single workgroup, deterministic. */
+hs_status hs_kan_regularization(const float* w, int64_t rows, int32_t coeffs, float reg_activation, float reg_entropy,
+                                float* loss, float* dw, void* stream);
+
 /* SupConLoss(temperature) on (B, D) features, mean over anchors, loss + d/d features
    (reference scripts/train.py:23-44).  ws: hs_supcon_ws_bytes(B, D). */
 hs_status hs_supcon_loss(const float* feat, const int64_t* labels, int32_t B, int32_t D, float temperature, float* loss,

@@ -72,10 +72,7 @@ class KANLinear(torch.nn.Module):
         raise NotImplementedError("update_grid (data-dependent re-gridding, kan1.py:167-212) is not part of the per-batch path")
 
     def regularization_loss(self, regularize_activation=1.0, regularize_entropy=1.0):
-        l1 = self.spline_weight.abs().mean(-1)
-        act = l1.sum()
-        p = l1 / act
-        return regularize_activation * act + regularize_entropy * (-(p * p.log()).sum())
+        return K.kan_regularization(self.spline_weight, regularize_activation, regularize_entropy)
 
 
 class KAN1(torch.nn.Module):

@@ -394,6 +394,48 @@ __global__ __launch_bounds__(256) void supcon_kernel(const float* __restrict__ f
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// KANLinear.regularization_loss (reference ConNexT/models/block/kan1.py:216-236):
+//   l_j = mean_c |w[j][c]| over the spline coefficients;  A = sum_j l_j;  p_j = l_j / A;  E = -sum_j p_j log p_j
+//   loss = ra * A + re * E;      d loss / d l_k = ra - re * (log p_k + E) / A
+// One workgroup, three strided passes (deterministic); rows = out*in, C = coefficients per row.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(256) void kan_regularization_kernel(const float* __restrict__ w, long long rows, int C, float ra,
+                                                                 float re, float* __restrict__ loss, float* __restrict__ dw) {
+    __shared__ float sh[4];
+    const float invc = 1.f / (float)C;
+    float a = 0.f, s = 0.f;
+    for (long long j = threadIdx.x; j < rows; j += 256) {
+        float l = 0.f;
+        for (int c = 0; c < C; ++c) l += fabsf(w[j * C + c]);
+        l *= invc;
+        a += l;
+        s += l > 0.f ? l * __logf(l) : 0.f;
+    }
+    const float A = block_sum256(a, sh);
+    const float S = block_sum256(s, sh);          // sum l log l
+    const float E = __logf(A) - S / A;
+    if (threadIdx.x == 0 && loss) loss[0] = ra * A + re * E;
+    if (!dw) return;
+    for (long long j = threadIdx.x; j < rows; j += 256) {
+        float l = 0.f;
+        for (int c = 0; c < C; ++c) l += fabsf(w[j * C + c]);
+        l *= invc;
+        const float dl = ra - re * ((l > 0.f ? __logf(l / A) : 0.f) + E) / A;
+        for (int c = 0; c < C; ++c) {
+            const float v = w[j * C + c];
+            dw[j * C + c] = v > 0.f ? dl * invc : (v < 0.f ? -dl * invc : 0.f);
+        }
+    }
+}
 }  // namespace hs
 
 using namespace hs;
@@ -493,4 +535,12 @@ hs_status hs_supcon_loss(const float* feat, const int64_t* labels, int32_t B, in
     return HS_OK;
 }
 int64_t hs_supcon_ws_bytes(int32_t B, int32_t D) { return ((int64_t)B * D + 2ll * B * B + B) * 4; }
+hs_status hs_kan_regularization(const float* w, int64_t rows, int32_t coeffs, float reg_activation, float reg_entropy,
+                                float* loss, float* dw, void* stream) {
+    HS_REQUIRE(w && rows > 0 && coeffs > 0 && (loss || dw), "kan_regularization: bad argument");
+    hipLaunchKernelGGL(kan_regularization_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w, rows, coeffs, reg_activation,
+                       reg_entropy, loss, dw);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
 }

@@ -29,6 +29,7 @@ def _l():
         l.hs_moe_combine_bwd.argtypes = [vp, C.POINTER(vp), vp, C.POINTER(vp), vp, i32, i32, i32, vp]
         l.hs_supcon_loss.argtypes = [vp, vp, i32, i32, f32, vp, vp, vp, vp]
         l.hs_supcon_ws_bytes.argtypes = [i32, i32]
+        l.hs_kan_regularization.argtypes = [vp, i64, i32, f32, f32, vp, vp, vp]
         l.hs_supcon_ws_bytes.restype = i64
         l.hs_mul_dev_scalar.argtypes = [vp, vp, vp, i64, vp]
         _declared = True
@@ -221,3 +222,34 @@ class SupConFn(Function):
 
 def supcon_loss(features, labels, temperature=0.07):
     return SupConFn.apply(features, labels, float(temperature))
+
+
+class KANRegularizationFn(Function):
+    """KANLinear.regularization_loss on spline_weight (out, in, coeffs): scalar loss with its gradient (one kernel each)"""
+
+    @staticmethod
+    def forward(ctx, w, ra, re):
+        rt.need_gpu(w)
+        w = w.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=w.device)
+        L.check(_l().hs_kan_regularization(rt.p(w), w.numel() // w.shape[-1], w.shape[-1], ra, re, rt.p(loss), None, rt.stream()),
+                "hs_kan_regularization")
+        ctx.save_for_backward(w)
+        ctx.meta = (ra, re)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        ra, re = ctx.meta
+        dw = torch.empty_like(w)
+        L.check(_l().hs_kan_regularization(rt.p(w), w.numel() // w.shape[-1], w.shape[-1], ra, re, None, rt.p(dw), rt.stream()),
+                "hs_kan_regularization")
+        g = g.contiguous().float()
+        out = torch.empty_like(dw)
+        L.check(_l().hs_mul_dev_scalar(rt.p(dw), rt.p(g), rt.p(out), dw.numel(), rt.stream()), "hs_mul_dev_scalar")
+        return out, None, None
+
+
+def kan_regularization(spline_weight, regularize_activation=1.0, regularize_entropy=1.0):
+    return KANRegularizationFn.apply(spline_weight, float(regularize_activation), float(regularize_entropy))

@@ -667,3 +667,26 @@ def test_bert_dropout_forward_and_backward_share_their_masks():
         numeric = (up - dn) / (2 * eps)
         assert abs(numeric - analytic) <= 3e-2 * max(abs(analytic), abs(numeric)) + 2e-3, (k, analytic, numeric)
     rt.reset_seed(None)
+
+
+def test_kan_regularization_loss_matches_torch():
+    """KANLinear.regularization_loss (kan1.py:216-236): value and gradient against the formula evaluated with torch on
+    the CPU; KAN1 sums its layers."""
+    from ConNexT.models.block.kan1 import KAN1
+    m = load_procedural(KAN1([16, 24, 8]), 5)
+    ref = 0.0
+    ws = []
+    for layer in m.layers:
+        w = layer.spline_weight.detach().clone().requires_grad_(True)
+        l1 = w.abs().mean(-1)
+        act = l1.sum()
+        pr = l1 / act
+        ref = ref + 0.7 * act + 1.3 * (-(pr * pr.log()).sum())
+        ws.append(w)
+    ref.backward()
+    m = m.to(DEV)
+    loss = m.regularization_loss(0.7, 1.3)
+    loss.backward()
+    _close(loss, ref, "kan regularization", 1e-5)
+    for layer, w in zip(m.layers, ws):
+        _close(layer.spline_weight.grad, w.grad, "kan regularization grad", 1e-4, 1e-7)
