@@ -82,7 +82,7 @@ def gpu_leg(args, rank, world, local_rank):
     net = net.to(device).train()
     nparams = sum(p.numel() for p in net.parameters())
     ddp = None
-    if world > 1:
+    if world > 1 or os.environ.get("HAMSPINE_FORCE_DDP") == "1":   # the latter: hook / bucket overhead without collectives
         from hamspine.ddp import DataParallel
         ddp = DataParallel(net)
     # overlap_backward (updates enqueued while backward runs) measured 17.0 vs 16.7 ms/step here: the HBM-bound update
