@@ -180,6 +180,20 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
             HS_REQUIRE(g.K % bk == 0, "conv dgrad: Kout %% %d != 0", bk);
             a.div_mhw = make_fastdiv(g.H * g.W);
             a.div_mw = make_fastdiv(g.W);
+            // stride 2: parity-major row order lets the kernel skip the 3/4 of the filter taps that cannot reach a given
+            // input pixel (HAMSPINE_PARITY_DGRAD=0 keeps the natural order)
+            static int parity_on = -1;
+            if (parity_on < 0) {
+                const char* e = getenv("HAMSPINE_PARITY_DGRAD");
+                parity_on = (e && e[0] == '0') ? 0 : 1;
+            }
+            if (parity_on && bf16 && g.stride == 2 && g.H % 2 == 0 && g.W % 2 == 0 && g.R * g.S <= 15 && split == 1 && batch == 1 &&
+                !p->seg_rows && !p->colstats) {
+                a.parity = 1;
+                a.quarter = g.N * (g.H / 2) * (g.W / 2);
+                a.div_qhw = make_fastdiv((g.H / 2) * (g.W / 2));
+                a.div_qw = make_fastdiv(g.W / 2);
+            }
         } else {
             HS_REQUIRE(p->K == g.N * g.P * g.Q, "conv wgrad: K != N*P*Q");
             HS_REQUIRE(p->N == g.R * g.S * g.C, "conv wgrad: N != R*S*C");

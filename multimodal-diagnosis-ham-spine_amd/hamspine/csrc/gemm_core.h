@@ -33,6 +33,10 @@ struct GemmArgs {
     long long a_bs0, a_bs1, b_bs0, b_bs1, d_bs0, d_bs1;   // in elements
     int tiles_m, tiles_n;
     int group_m;               // tile rows per L2 group (tile_from_block)
+    // stride-2 dgrad: rows ordered by input-pixel parity class so a tile's structurally-zero filter taps can be skipped
+    int parity;                // 1: row m = class * quarter + (n, i, j), pixel (2i + class/2, 2j + class%2)
+    int quarter;               // N * (H/2) * (W/2)
+    FastDiv div_qhw, div_qw;   // divide by (H/2)*(W/2), W/2
     float* colstats;           // optional per (row tile, column) (count, mean, M2) of the result (fused BatchNorm statistics)
     int lds_stages;            // ring slots actually allocated: min(3, K tiles per workgroup) (bf16 kernel)
     int split_k;               // >1: blockIdx.z is the split index
@@ -59,6 +63,26 @@ struct GemmArgs {
     int seg_rows;              // >0: output rows are split over D / D_seg[0] / D_seg[1]
     char* D_seg[2];
 };
+
+// parity-major row order of a stride-2 dgrad: permuted row m -> (image, input pixel)
+__device__ __forceinline__ int parity_class(const GemmArgs& a, int m) {
+    return (m >= a.quarter) + (m >= 2 * a.quarter) + (m >= 3 * a.quarter);
+}
+__device__ __forceinline__ void parity_pixel(const GemmArgs& a, int m, unsigned& n, unsigned& h, unsigned& w) {
+    const int cls = parity_class(a, m);
+    const unsigned idx = m - cls * a.quarter;
+    n = fdiv(idx, a.div_qhw);
+    const unsigned ij = idx - n * a.div_qhw.d;
+    const unsigned i = fdiv(ij, a.div_qw);
+    h = 2 * i + (cls >> 1);
+    w = 2 * (ij - i * a.div_qw.d) + (cls & 1);
+}
+__device__ __forceinline__ long long parity_row(const GemmArgs& a, int m) {   // natural (n, h, w) row index
+    unsigned n, h, w;
+    parity_pixel(a, m, n, h, w);
+    return ((long long)n * a.g.H + h) * a.g.W + w;
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // epilogue for 4 consecutive n of one row m.  TIn = element type of mul_src; TOut chosen at run time.
@@ -103,6 +127,7 @@ __device__ __forceinline__ void store4(char* base, long long idx, bool vec, int 
 template <typename T>
 __device__ __forceinline__ void epilogue4(const GemmArgs& a, long long dbase, int z, int m, int n, float* v) {
     if (m >= a.M || n >= a.N) return;
+    const long long mr = a.parity ? parity_row(a, m) : (long long)m;   // row of D / residual / multiplier source
     const int nvalid = min(4, a.N - n);
     const bool vec = a.vec_store && nvalid == 4;
 #pragma unroll
@@ -114,7 +139,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, long long dbase, in
     }
     if (a.mul_mode != HS_MUL_NONE) {
         float u[4];
-        load4<T>(a.mul_src, (long long)m * a.ldm + n, vec, nvalid, u);   // mul_src is never batched
+        load4<T>(a.mul_src, mr * a.ldm + n, vec, nvalid, u);   // mul_src is never batched
         if (a.mul_mode == HS_MUL_GELU_GRAD) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] *= gelu_grad_t<T>(u[j]);
@@ -124,7 +149,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, long long dbase, in
         }
     }
     char* Dp = a.D;
-    long long didx = dbase + (long long)m * a.ldd + n;
+    long long didx = dbase + mr * a.ldd + n;
     if (a.seg_rows > 0) {
         const int seg = m / a.seg_rows;
         if (seg > 0) Dp = a.D_seg[seg - 1];
@@ -155,7 +180,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, long long dbase, in
     }
     if (a.residual) {
         float r[4];
-        const long long ridx = dbase + (long long)m * a.ldr + n;   // residual shares D's batch strides
+        const long long ridx = dbase + mr * a.ldr + n;   // residual shares D's batch strides
         if (a.out_f32) load4<float>(a.residual, ridx, vec, nvalid, r);
         else load4<T>(a.residual, ridx, vec, nvalid, r);
 #pragma unroll
@@ -221,11 +246,16 @@ __device__ __forceinline__ void kc_row_setup(const GemmArgs& a, int m, KcRow<KIN
         st.hb = (int)p * a.g.stride - a.g.pad;
         st.wb = (int)q * a.g.stride - a.g.pad;
         st.base = (int)n * a.g.img_pitch + st.hb * a.g.row_pitch + (int)q * a.g.qstep - a.g.pad * a.g.C;
-    } else {   // HS_A_DGRAD: m = (n, h, w) over the conv INPUT grid
-        const unsigned n = fdiv(m, a.div_mhw);
-        const unsigned hw = m - n * a.div_mhw.d;
-        const unsigned h = fdiv(hw, a.div_mw);
-        const unsigned w = hw - h * a.div_mw.d;
+    } else {   // HS_A_DGRAD: m = (n, h, w) over the conv INPUT grid (or its parity-major permutation)
+        unsigned n, h, w;
+        if (a.parity) {
+            parity_pixel(a, st.valid ? m : 0, n, h, w);
+        } else {
+            n = fdiv(m, a.div_mhw);
+            const unsigned hw = m - n * a.div_mhw.d;
+            h = fdiv(hw, a.div_mw);
+            w = hw - h * a.div_mw.d;
+        }
         st.hb = (int)h + a.g.pad;
         st.wb = (int)w + a.g.pad;
         st.base = (int)n * a.g.P * a.g.Q * a.g.K;
@@ -520,7 +550,39 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
     //    hides under 8..16 MFMAs instead of stalling every MFMA pair.
     constexpr int NDMA = A_NI + B_NI;
     constexpr int KS = BK / 32;
-    const int ntiles = (kend - kbeg + BK - 1) / BK;
+    int ntiles = (kend - kbeg + BK - 1) / BK;
+    // stride-2 dgrad with parity-major rows: when every row of this tile is in one parity class, only the filter taps
+    // (r, s) with (class_h + pad - r) and (class_w + pad - s) even can reach a stored output pixel; the K walk keeps just
+    // those taps (1, 2, 2 or 4 of 9 for a 3x3 filter; 1 or 0 of 1 for a 1x1).  taps: 4 bits per kept tap index.
+    unsigned long long taps = 0;
+    int tiles_per_tap = 1;
+    bool filtered = false;
+    if constexpr (AK == HS_A_DGRAD) {
+        if (a.parity) {
+            const int c_first = parity_class(a, m0), c_last = parity_class(a, min(m0 + BM, a.M) - 1);
+            if (c_first == c_last) {
+                filtered = true;
+                tiles_per_tap = a.g.K / BK;
+                int kept = 0;
+                for (int r = 0; r < a.g.R; ++r)
+                    for (int q = 0; q < a.g.S; ++q)
+                        if ((((c_first >> 1) + a.g.pad - r) & 1) == 0 && (((c_first & 1) + a.g.pad - q) & 1) == 0) {
+                            taps |= (unsigned long long)(r * a.g.S + q) << (4 * kept);
+                            ++kept;
+                        }
+                ntiles = kept * tiles_per_tap;
+            }
+        }
+    }
+    auto k_of = [&](int t) -> int {          // first k of the t-th tile of this workgroup's K walk
+        if constexpr (AK == HS_A_DGRAD) {
+            if (filtered) {
+                const int ti = t / tiles_per_tap;
+                return (int)((taps >> (4 * ti)) & 15) * a.g.K + (t - ti * tiles_per_tap) * BK;
+            }
+        }
+        return kbeg + t * BK;
+    };
 
     auto load_frags = [&](int slot, int ks, bf16x8 (&af)[FM], bf16x8 (&bfr)[FN]) {
         const char* sa = smem + slot * STAGE;
@@ -571,14 +633,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
         if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (t + 3 < ntiles) stage_dma(cur, kbeg + (t + 3) * BK);
+        if (t + 3 < ntiles) stage_dma(cur, k_of(t + 3));
         cur = cur == 2 ? 0 : cur + 1;
     };
 
     if (ntiles > 0) {
-        stage_dma(0, kbeg);
-        if (ntiles > 1) stage_dma(1, kbeg + BK);
-        if (ntiles > 2) stage_dma(2, kbeg + 2 * BK);
+        stage_dma(0, k_of(0));
+        if (ntiles > 1) stage_dma(1, k_of(1));
+        if (ntiles > 2) stage_dma(2, k_of(2));
         if (ntiles > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
         else if (ntiles > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
