@@ -269,7 +269,16 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     dim3 grid(a.tiles_m * a.tiles_n, 1, split > 1 ? split : batch);
     int st;
     ProfRec rec;
-    const bool timed = prof_begin(stream, 2.0 * p->M * p->N * (double)p->K * batch, (bf16 ? 0 : 2) + (conv ? 1 : 0), rec);
+    double flops = 2.0 * p->M * p->N * (double)p->K * batch;
+    if (a.parity) {   // strided dgrad: only the (pixel parity, filter tap) pairs that reach an output pixel are real work
+        int kept = 0;
+        for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < p->g.R; ++r)
+                for (int q = 0; q < p->g.S; ++q)
+                    kept += ((((c >> 1) + p->g.pad - r) & 1) == 0 && (((c & 1) + p->g.pad - q) & 1) == 0) ? 1 : 0;
+        flops *= (double)kept / (4.0 * p->g.R * p->g.S);
+    }
+    const bool timed = prof_begin(stream, flops, (bf16 ? 0 : 2) + (conv ? 1 : 0), rec);
     if (bf16) st = conv ? launch_bf16_conv(cfg, combo, a, grid, stream) : launch_bf16_plain(cfg, combo, a, grid, stream);
     else st = conv ? launch_f32_conv(cfg, combo, a, grid, stream) : launch_f32_plain(cfg, combo, vec, a, grid, stream);
     if (timed) {
