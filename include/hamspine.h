@@ -106,6 +106,11 @@ typedef struct hs_gemm_params {
        rebased), rows below seg_rows to D.  Lets one GEMM write three parameter gradients (fused QKV wgrad). */
     int32_t seg_rows;
     void* D_seg[2];
+    /* optional per-column scale applied before the bias: v = alpha * acc * colscale[n] + bias[n] (an eval-mode BatchNorm
+       folded into the convolution), and residual_before_act = 1 to add `residual` before the activation
+       (y = relu(bn(conv) + identity)) instead of after it */
+    const float* colscale;
+    int32_t residual_before_act;
     /* optional (bf16 operands, no split-K, no batching): per (row tile, column) statistics of the result for a following
        BatchNorm, written as (count, mean, M2) triples to colstats[(tile_row * N + n) * 3 ...]; hs_gemm_stat_rows(p) gives
        the number of tile rows.  Saves BatchNorm's own pass over the convolution output (hs_bn_params.partial_rows). */
@@ -271,6 +276,13 @@ hs_status hs_cross_entropy(const float* logits, const int64_t* labels, const flo
 hs_status hs_adam_step_multi(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
                              float* const* exp_avg_sq, const int64_t* n, float lr, float beta1, float beta2, float eps,
                              float weight_decay, int32_t step, int32_t decoupled, float grad_scale, void* stream);
+
+/* fused multi-tensor SGD, torch.optim.SGD semantics (the reference's fallback optimizer, scripts/train.py:309):
+   g += wd*p; buf = first ? g : momentum*buf + g; g = nesterov ? g + momentum*buf : buf; p -= lr*g.  momentum_buf may be
+   NULL when momentum == 0. */
+hs_status hs_sgd_step_multi(int32_t count, float* const* params, const float* const* grads, float* const* momentum_buf,
+                            const int64_t* n, float lr, float momentum, float weight_decay, int32_t nesterov, int32_t first,
+                            float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------- */
 /* small f32 operators at the fusion / head / loss boundary                                       */
@@ -464,6 +476,9 @@ typedef struct hs_resblock_desc {
     hs_conv_bn main[3];
     int32_t has_ds;
     hs_conv_bn ds;
+    int32_t inference;            /* 1 (only with training = 0): no backward follows -- every BatchNorm is folded into
+                                     its convolution's epilogue (scale, shift, ReLU, identity add) and only the weight
+                                     casts use `saved`                                                 */
 } hs_resblock_desc;
 hs_status hs_resblock_query(const hs_resblock_desc* d, int64_t* saved_bytes, int64_t* ws_bytes);
 hs_status hs_resblock_fwd(const hs_resblock_desc* d, const void* x, void* y, void* saved, int64_t saved_bytes, void* ws,
@@ -480,6 +495,7 @@ typedef struct hs_stem_desc {
     int32_t training;
     float eps, momentum;
     hs_conv_bn cb;                /* Cin = 3, Cout = 64, R = 7, stride = 2, pad = 3                */
+    int32_t inference;            /* as hs_resblock_desc.inference                                 */
 } hs_stem_desc;
 hs_status hs_stem_query(const hs_stem_desc* d, int64_t* saved_bytes, int64_t* ws_bytes);
 hs_status hs_stem_fwd(const hs_stem_desc* d, const float* image, void* y, void* saved, int64_t saved_bytes, void* ws,

@@ -51,7 +51,7 @@ class GemmParams(C.Structure):
         ("dropout_p", f32), ("dropout_seed", u64),
         ("mul_mode", i32), ("mul_src", vp), ("ldm", i32),
         ("accumulate", i32),
-        ("seg_rows", i32), ("D_seg", vp * 2), ("colstats", vp),
+        ("seg_rows", i32), ("D_seg", vp * 2), ("colscale", vp), ("residual_before_act", i32), ("colstats", vp),
     ]
 
 
@@ -94,14 +94,14 @@ class ResblockDesc(C.Structure):
     _fields_ = [
         ("dtype", i32), ("N", i32), ("H", i32), ("W", i32), ("training", i32),
         ("eps", f32), ("momentum", f32), ("n_main", i32), ("main", ConvBn * 3),
-        ("has_ds", i32), ("ds", ConvBn),
+        ("has_ds", i32), ("ds", ConvBn), ("inference", i32),
     ]
 
 
 class StemDesc(C.Structure):
     _fields_ = [
         ("dtype", i32), ("N", i32), ("H", i32), ("W", i32), ("training", i32),
-        ("eps", f32), ("momentum", f32), ("cb", ConvBn),
+        ("eps", f32), ("momentum", f32), ("cb", ConvBn), ("inference", i32),
     ]
 
 
@@ -179,6 +179,7 @@ def _declare(l):
     l.hs_bert_embed_bwd.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     l.hs_cross_entropy.argtypes = [vp, vp, vp, f32, i32, i32, vp, vp, vp, vp]
     l.hs_adam_step_multi.argtypes = [i32, P(vp), P(vp), P(vp), P(vp), P(i64), f32, f32, f32, f32, f32, i32, i32, f32, vp]
+    l.hs_sgd_step_multi.argtypes = [i32, P(vp), P(vp), P(vp), P(i64), f32, f32, f32, i32, i32, f32, vp]
     l.hs_attention_query.argtypes = [P(AttnDesc), P(i64), P(i64)]
     l.hs_attention_fwd.argtypes = [P(AttnDesc), vp, vp, vp, vp, vp, i64, vp, i64, vp]
     l.hs_attention_bwd.argtypes = [P(AttnDesc), vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp]

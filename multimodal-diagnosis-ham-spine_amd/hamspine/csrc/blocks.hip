@@ -434,9 +434,23 @@ static bool fused_bn_stats_enabled() {     // HAMSPINE_FUSED_BN_STATS=0: BatchNo
 
 // stats (optional, bf16 mode): receives the (count, mean, M2) partials of y per row tile for the BatchNorm that follows;
 // *stat_rows is set to the number of partial rows (0: not produced, BatchNorm makes its own pass)
+struct FoldedBn {          // eval-mode BatchNorm folded into the convolution: y = act(conv * scale + shift (+ identity))
+    const float* scale = nullptr;
+    const float* shift = nullptr;
+    int relu = 0;
+    const void* identity = nullptr;
+};
 static int conv_fwd_run(Run& r, const ConvShape& s, const void* x, const void* w_c, void* y, float* stats = nullptr,
-                        int* stat_rows = nullptr) {
+                        int* stat_rows = nullptr, const FoldedBn* fold = nullptr) {
     hs_gemm_params p = gemm_defaults(r.dt);
+    if (fold) {
+        p.colscale = fold->scale;
+        p.bias = fold->shift;
+        p.act = fold->relu ? HS_ACT_RELU : HS_ACT_NONE;
+        p.residual = fold->identity;
+        p.ldr = s.Cout;
+        p.residual_before_act = 1;
+    }
     const long long Mo = (long long)s.N * s.P * s.Q;
     p.M = (int)Mo; p.N = s.Cout; p.K = s.R * s.R * s.Cin;
     p.A = x; p.B = w_c;
@@ -586,6 +600,31 @@ static int resblock_fwd_run(Run& r, const hs_resblock_desc& d, const void* x, vo
     RUN_CHECK_ARENAS(r, "resblock_fwd");
     HS_PROPAGATE(run_casts(r, L.casts));
     const void* identity = x;
+    if (d.inference && !d.training) {
+        // no backward follows: scale/shift from the running statistics, then ONE GEMM per convolution with BatchNorm,
+        // ReLU and the identity add in its epilogue
+        auto folded = [&](const hs_conv_bn& cb, StageBuf& b, const void* in, void* out, int relu, const void* ident) -> int {
+            const long long Mo = (long long)d.N * b.s.P * b.s.Q;
+            hs_bn_params bp = bn_params(r, d, cb, b, Mo);
+            bp.y = nullptr;                                   // statistics only: fills b.scale / b.shift
+            bp.ws = L.bn_ws; bp.ws_bytes = L.bn_ws_bytes;
+            CALL(r, hs_batchnorm_fwd(&bp, r.s));
+            FoldedBn f;
+            f.scale = b.scale; f.shift = b.shift; f.relu = relu; f.identity = ident;
+            return conv_fwd_run(r, b.s, in, b.w_c, out, nullptr, nullptr, &f);
+        };
+        if (d.has_ds) {
+            HS_PROPAGATE(folded(d.ds, L.ds, x, L.ds.a, 0, nullptr));
+            identity = L.ds.a;
+        }
+        const void* in = x;
+        for (int i = 0; i < d.n_main; ++i) {
+            const bool last = i + 1 == d.n_main;
+            HS_PROPAGATE(folded(d.main[i], L.main[i], in, last ? y : L.main[i].a, 1, last ? identity : nullptr));
+            in = L.main[i].a;
+        }
+        return HS_OK;
+    }
     if (d.has_ds) {
         const long long Mo = (long long)d.N * L.ds.s.P * L.ds.s.Q;
         int srows = 0;
@@ -757,6 +796,21 @@ static int stem_fwd_run(Run& r, const hs_stem_desc& d, const float* image, void*
     p.ldb = 224;
     p.g = L.g;
     p.D = L.c; p.ldd = cb.Cout;
+    if (d.inference && !d.training) {
+        hs_bn_params be;
+        memset(&be, 0, sizeof(be));
+        be.dtype = r.dt; be.C = cb.Cout; be.M = Mo; be.training = 0; be.eps = d.eps; be.momentum = d.momentum;
+        be.x = L.c; be.y = nullptr;
+        be.gamma = cb.gamma; be.beta = cb.beta; be.running_mean = cb.running_mean; be.running_var = cb.running_var;
+        be.save_mean = L.mean; be.save_invstd = L.invstd; be.scale = L.scale; be.shift = L.shift;
+        be.ws = L.bn_ws; be.ws_bytes = L.bn_ws_bytes;
+        CALL(r, hs_batchnorm_fwd(&be, r.s));
+        p.colscale = L.scale; p.bias = L.shift; p.act = HS_ACT_RELU;
+        p.D = L.a;                                            // BatchNorm + ReLU folded: the GEMM writes the pooled input
+        CALL(r, gemm_impl(&p, r.s));
+        CALL(r, hs_maxpool_fwd(r.dt, L.a, y, L.idx, d.N, L.P, L.Q, cb.Cout, 3, 2, 1, r.s));
+        return HS_OK;
+    }
     int srows = 0;
     if (d.training && fused_bn_stats_enabled() && (srows = gemm_stat_rows(&p)) > 0) p.colstats = (float*)L.bn_ws;
     CALL(r, gemm_impl(&p, r.s));

@@ -785,6 +785,28 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable t, floa
     }
 }
 
+// fused multi-tensor SGD (torch.optim.SGD semantics: weight decay added to the gradient, optional momentum buffer with
+// dampening 0, optional Nesterov); `first` = the momentum buffers are uninitialised (torch seeds them with the gradient)
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const AdamTable t, float lr, float momentum, float wd, int nesterov,
+                                                        int first, float grad_scale) {
+    const int e = blockIdx.y;
+    float* p = t.p[e];
+    const float* g = t.g[e];
+    float* buf = t.m[e];            // NULL when momentum == 0
+    const long long n = t.n[e];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float gi = g[i] * grad_scale;
+        const float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        if (buf) {
+            const float b = first ? gi : momentum * buf[i] + gi;
+            buf[i] = b;
+            gi = nesterov ? gi + momentum * b : b;
+        }
+        p[i] = pi - lr * gi;
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // host wrappers
 // --------------------------------------------------------------------------------------------
@@ -1124,6 +1146,29 @@ hs_status hs_cross_entropy(const float* logits, const int64_t* labels, const flo
     hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, (const long long*)labels, weight,
                        label_smoothing, B, C, loss, dlogits, row_loss);
     HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_sgd_step_multi(int32_t count, float* const* params, const float* const* grads, float* const* momentum_buf,
+                            const int64_t* n, float lr, float momentum, float weight_decay, int32_t nesterov, int32_t first,
+                            float grad_scale, void* stream) {
+    HS_REQUIRE(count >= 0 && (momentum == 0.f || momentum_buf), "sgd: bad argument");
+    for (int base = 0; base < count; base += HS_ADAM_MAX) {
+        AdamTable t;
+        memset(&t, 0, sizeof(t));
+        const int cnt = std::min(HS_ADAM_MAX, count - base);
+        long long mx = 0;
+        for (int i = 0; i < cnt; ++i) {
+            t.p[i] = params[base + i];
+            t.g[i] = grads[base + i];
+            t.m[i] = momentum != 0.f ? momentum_buf[base + i] : nullptr;
+            t.n[i] = n[base + i];
+            mx = std::max<long long>(mx, t.n[i]);
+        }
+        const int gx = (int)std::min<long long>(std::max<long long>((mx + 1023) / 1024, 1), 512);
+        hipLaunchKernelGGL(sgd_multi_kernel, dim3(gx, cnt), dim3(256), 0, (hipStream_t)stream, t, lr, momentum, weight_decay,
+                           nesterov, first, grad_scale);
+        HS_LAUNCH_CHECK();
+    }
     return HS_OK;
 }
 hs_status hs_adam_step_multi(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,

@@ -145,6 +145,8 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     a.ldm = p->ldm;
     a.accumulate = p->accumulate;
     a.colstats = p->colstats;
+    a.colscale = p->colscale;
+    a.res_pre_act = p->residual_before_act;
     a.seg_rows = p->seg_rows;
     a.D_seg[0] = (char*)p->D_seg[0];
     a.D_seg[1] = (char*)p->D_seg[1];

@@ -37,6 +37,8 @@ struct GemmArgs {
     int parity;                // 1: row m = class * quarter + (n, i, j), pixel (2i + class/2, 2j + class%2)
     int quarter;               // N * (H/2) * (W/2)
     FastDiv div_qhw, div_qw;   // divide by (H/2)*(W/2), W/2
+    const float* colscale;     // optional per-column scale before the bias (folded eval-mode BatchNorm)
+    int res_pre_act;           // residual is added before the activation
     float* colstats;           // optional per (row tile, column) (count, mean, M2) of the result (fused BatchNorm statistics)
     int lds_stages;            // ring slots actually allocated: min(3, K tiles per workgroup) (bf16 kernel)
     int split_k;               // >1: blockIdx.z is the split index
@@ -132,6 +134,11 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, long long dbase, in
     const bool vec = a.vec_store && nvalid == 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] *= a.alpha;
+    if (a.colscale) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < nvalid) v[j] *= a.colscale[n + j];
+    }
     if (a.bias) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -159,6 +166,14 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, long long dbase, in
         if (a.out_f32) store4<float>(a.D_preact, didx, vec, nvalid, v);
         else store4<T>(a.D_preact, didx, vec, nvalid, v);
     }
+    if (a.residual && a.res_pre_act) {
+        float r[4];
+        const long long ridx = dbase + mr * a.ldr + n;
+        if (a.out_f32) load4<float>(a.residual, ridx, vec, nvalid, r);
+        else load4<T>(a.residual, ridx, vec, nvalid, r);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += r[j];
+    }
     if (a.act == HS_ACT_RELU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -178,7 +193,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, long long dbase, in
             for (int j = 0; j < 4; ++j) v[j] *= dropout_scale(a.drop_seed, e + j, a.drop_thresh, a.drop_inv_keep);
         }
     }
-    if (a.residual) {
+    if (a.residual && !a.res_pre_act) {
         float r[4];
         const long long ridx = dbase + mr * a.ldr + n;   // residual shares D's batch strides
         if (a.out_f32) load4<float>(a.residual, ridx, vec, nvalid, r);

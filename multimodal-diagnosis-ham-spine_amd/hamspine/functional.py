@@ -65,6 +65,8 @@ class StemFn(Function):
         d.N, d.H, d.W = N, H, W
         d.training = 1 if cfg["training"] else 0
         d.eps, d.momentum = cfg["eps"], cfg["momentum"]
+        # no gradient will be asked for (inference under no_grad): BatchNorm folds into the convolution epilogue
+        d.inference = 0 if (cfg["training"] or any(ctx.needs_input_grad)) else 1
         geo = (Cin, weight.shape[0], 7, 2, 3)
         _fill_cb(d.cb, geo, w, gamma, beta, cfg["running_mean"], cfg["running_var"])
         sv_b, ws_b = rt.query(_lib().hs_stem_query, d)
@@ -134,6 +136,7 @@ class ResBlockFn(Function):
         for i in range(0, len(params), 3):
             params[i] = _cl_weight(params[i])
         d = ResBlockFn._desc(cfg, x.shape, params)
+        d.inference = 0 if (cfg["training"] or any(ctx.needs_input_grad)) else 1
         sv_b, ws_b = rt.query(_lib().hs_resblock_query, d)
         saved = torch.empty(sv_b, dtype=torch.uint8, device=x.device)
         ws = rt.workspace(ws_b, x.device)

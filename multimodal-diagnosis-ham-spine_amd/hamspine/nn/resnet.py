@@ -181,9 +181,10 @@ class ResNet(nn.Module):
         x = self.features(x)
         N, Cc, H, W = x.shape
         tokens = x.permute(0, 2, 3, 1).reshape(N, H * W, Cc)   # a view: the memory already is NHWC
-        pooled = F.mean_tokens(tokens, out_f32=False)          # global average pool
         if isinstance(self.fc, nn.Identity):
-            return pooled
+            return F.mean_tokens(tokens, out_f32=False)        # global average pool
+        # a class count that is not a multiple of 8 cannot be a bf16 leading dimension: such an fc runs in f32
+        pooled = F.mean_tokens(tokens, out_f32=self.fc.out_features % 8 != 0)
         return self.fc(pooled, out_dtype=torch.float32)   # logits / embeddings leave the tower as f32
 
 

@@ -152,3 +152,50 @@ class FusedAdamW(_FusedAdamBase):
 
 class FusedAdam(_FusedAdamBase):
     _decoupled = False
+
+
+class FusedSGD(torch.optim.Optimizer):
+    """torch.optim.SGD (weight decay, momentum with dampening 0, Nesterov) on hs_sgd_step_multi: the reference's fallback
+    optimizer (scripts/train.py:309).  Same hyper-parameters, param_groups and state_dict layout (momentum_buffer)."""
+
+    def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0, nesterov=False):
+        if nesterov and momentum <= 0:
+            raise ValueError("Nesterov momentum requires a momentum")
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov))
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = L.lib()
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            rt.need_gpu(*ps)
+            mom = float(group["momentum"])
+            # tensors seeing their first momentum step are seeded with the gradient (torch.optim.SGD): partition first
+            fresh = [p for p in ps if mom != 0 and "momentum_buffer" not in self.state[p]]
+            seen = [p for p in ps if not (mom != 0 and "momentum_buffer" not in self.state[p])]
+            for first, sel in ((True, fresh), (False, seen)):
+                if not sel:
+                    continue
+                n = len(sel)
+                for p in sel:
+                    if p.dtype != torch.float32 or p.grad.dtype != torch.float32:
+                        raise L.HamspineError("FusedSGD expects f32 parameters and gradients")
+                    if p.grad.stride() != p.stride():
+                        g2 = torch.empty_like(p, memory_format=torch.preserve_format)
+                        g2.copy_(p.grad)
+                        p.grad = g2
+                    if mom != 0 and first:
+                        self.state[p]["momentum_buffer"] = torch.empty_like(p, memory_format=torch.preserve_format)
+                arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+                bufs = arr([self.state[p]["momentum_buffer"] for p in sel]) if mom != 0 else None
+                cnt = (C.c_int64 * n)(*[p.numel() for p in sel])
+                L.check(lib.hs_sgd_step_multi(n, arr(sel), arr([p.grad for p in sel]), bufs, cnt, float(group["lr"]), mom,
+                                              float(group["weight_decay"]), 1 if group["nesterov"] else 0, 1 if first else 0,
+                                              float(grad_scale), rt.stream()), "hs_sgd_step_multi")
+        return loss
