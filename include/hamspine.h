@@ -554,6 +554,28 @@ hs_status hs_linear_bwd(int32_t dtype, const void* x, int64_t M, int32_t ldx, co
                         void* stream);
 int64_t hs_linear_bwd_ws_bytes(int64_t M, int32_t in_f, int32_t out_f, int32_t dtype);
 
+/* ------------------------------------------------------------------------------------------- */
+/* callers either side of the path: inference helpers and input staging     */
+/* ------------------------------------------------------------------------------------------- */
+/* Test-time augmentation as ONE batch (replaces the per-variant model calls of reference scripts/predict.py:33-42,
+   63-70): out[v] = op_v(x) over `planes` = B*C (or B*T*C) image planes of H x W f32.  ops[v]: 0 identity, 1 flip(-1)
+   ("hflip"), 2 flip(-2) ("vflip"), 3 torch.rot90(k=1, dims=(-2,-1)) (square planes only).  1 <= V <= 8. */
+hs_status hs_tta_expand(const float* x, float* out, int64_t planes, int32_t H, int32_t W, const int32_t* ops, int32_t V,
+                        void* stream);
+/* out[i] = mean over v of x[v*n + i]: torch.stack(logits_list, 0).mean(0) of scripts/predict.py:70. */
+hs_status hs_group_mean(const float* x, float* out, int32_t V, int64_t n, void* stream);
+/* out[v*n + i] = x[i]: tiles text tokens / ids / masks over the TTA variants (elements of 2, 4 or 8 bytes). */
+hs_status hs_repeat(int32_t elem_bytes, const void* x, void* out, int64_t n, int32_t V, void* stream);
+/* Grad-CAM map per image from one stage's activation and gradient, both [B][HW][C] (NHWC memory):
+   w = mean_hw(grad); cam = relu(sum_c w[c] * act[:, c]); cam /= max(cam) if max(cam) > 0.
+   Replaces the numpy loop of reference analysis_tools.py:78-93 (before its cv2.resize). */
+hs_status hs_gradcam(int32_t dtype, const void* act, const void* grad, float* cam, int32_t B, int32_t C, int32_t HW,
+                     void* stream);
+/* Input staging: decoded u8 images [B][H][W][3] -> f32 [B][3][H][W], (v/255 - mean[c]) / std[c] in IEEE f32
+   (torchvision ToTensor + Normalize of the reference's data pipeline, data_loader.py transforms). */
+hs_status hs_stage_images_u8(const uint8_t* src, float* out, int32_t B, int32_t H, int32_t W, const float* mean,
+                             const float* std, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

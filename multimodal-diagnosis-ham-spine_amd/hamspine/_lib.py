@@ -206,6 +206,11 @@ def _declare(l):
     l.hs_concat2_t.argtypes = [i32, vp, i32, vp, i32, vp, i64, vp]
     l.hs_split2_t.argtypes = [i32, vp, vp, i32, vp, i32, i64, vp]
     l.hs_prof_calibrate.argtypes = [vp, i32, C.POINTER(C.c_float)]
+    l.hs_tta_expand.argtypes = [vp, vp, i64, i32, i32, P(i32), i32, vp]
+    l.hs_group_mean.argtypes = [vp, vp, i32, i64, vp]
+    l.hs_repeat.argtypes = [i32, vp, vp, i64, i32, vp]
+    l.hs_gradcam.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
+    l.hs_stage_images_u8.argtypes = [vp, vp, i32, i32, i32, P(f32), P(f32), vp]
     l.hs_set_overlap.restype = None
     l.hs_dwconv_ws_bytes.argtypes = [i32] * 5
     l.hs_dwconv_ws_bytes.restype = i64
