@@ -10,6 +10,7 @@ once per epoch.
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -31,6 +32,13 @@ def normalize_u8(images_u8, mean=IMAGENET_MEAN, std=IMAGENET_STD):
     s = (C.c_float * 3)(*std)
     L.check(L.lib().hs_stage_images_u8(rt.p(x), rt.p(out), B, H, W, m, s, rt.stream()), "hs_stage_images_u8")
     return out
+
+
+def _host_copy(dst, src):
+    """one plain memcpy into the pinned buffer.  torch's `copy_` goes through the intra-op thread pool; on a host that
+    shows 128 hardware threads to a 16-core share, waking that pool between steps cost 20-35 ms per 19 MB batch
+    (measured, tools/inference_bench.py), against 0.4 ms for the memcpy."""
+    np.copyto(dst.reshape(-1).view(torch.uint8).numpy(), src.contiguous().reshape(-1).view(torch.uint8).numpy())
 
 
 class BatchStager:
@@ -63,7 +71,7 @@ class BatchStager:
             if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
                 buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
                 self._pinned[(slot, key)] = buf
-            buf.copy_(t)
+            _host_copy(buf, t)
             t = buf
         return t.to(self.device, non_blocking=True)
 
