@@ -7,6 +7,8 @@ namespace hs {
         case CFG_128x128: L(128, 128, 64, AK, BKD); \
         case CFG_128x64: L(128, 64, 64, AK, BKD);  \
         case CFG_64x64: L(64, 64, 64, AK, BKD);    \
+        case CFG_256x128:                          \
+            return launch_with_lds(gemm_bf16_kernel<256, 128, 64, AK, BKD, true, 4>, a.lds_stages * 384 * 64 * 2, 3 * 384 * 64 * 2, a, grid, s, 512); \
     }                                              \
     break;
 int launch_bf16_plain(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s) {

@@ -449,16 +449,18 @@ __device__ __forceinline__ int rc_logical_chunk(int k, int pcc) {
 // logical chunk belongs at this LDS slot) and again on the fragment reads.  Out-of-range source offsets
 // write zeros (verified on gfx950), which is how M/N/K tails and conv padding are predicated.
 // Contract for K-contiguous operands: K % 8 == 0, or the row is zero padded up to the next multiple of 8.
-template <int BM, int BN, int BK, int AK, int BKIND, bool VEC>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
+// WGM: waves along M (x 2 along N): 2 -> 256 threads (the default), 4 -> 512 threads for the 256-row tile.
+template <int BM, int BN, int BK, int AK, int BKIND, bool VEC, int WGM = 2>
+__global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) {
     typedef bf16_t T;
     constexpr int ESZ = 2;
     constexpr bool A_RC = a_is_rc(AK), B_RC = b_is_rc(BKIND);
-    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    constexpr int NW = 2 * WGM;
+    constexpr int WM = BM / WGM, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_NI = A_BYTES / 1024 / 4, B_NI = B_BYTES / 1024 / 4;   // DMA instructions per wave per tile
+    constexpr int A_NI = A_BYTES / 1024 / NW, B_NI = B_BYTES / 1024 / NW;   // DMA instructions per wave per tile
     constexpr int CPR = BK / 8;
-    static_assert(A_NI >= 1 && B_NI >= 1, "tile too small for 4 DMA waves");
+    static_assert(A_NI >= 1 && B_NI >= 1, "tile too small for its DMA waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) char lds_char;
 
@@ -714,7 +716,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
                 s2[j][e] = w;
             }
         __syncthreads();                       // every wave is done with the last tile's fragments
-        float* sh = (float*)smem;              // [2 row waves][BN][2]
+        float* sh = (float*)smem;              // [WGM row waves][BN][2]
         if (l15 == 0) {
 #pragma unroll
             for (int j = 0; j < FN; ++j)
@@ -727,7 +729,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
         }
         __syncthreads();
         if (tid < BN && n0 + tid < a.N) {
-            const float t1 = sh[tid * 2] + sh[(BN + tid) * 2], t2 = sh[tid * 2 + 1] + sh[(BN + tid) * 2 + 1];
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM; ++w) {
+                t1 += sh[(w * BN + tid) * 2];
+                t2 += sh[(w * BN + tid) * 2 + 1];
+            }
             const float cnt = (float)min(BM, a.M - m0);
             float* o = a.colstats + ((long long)tm * a.N + n0 + tid) * 3;
             o[0] = cnt;

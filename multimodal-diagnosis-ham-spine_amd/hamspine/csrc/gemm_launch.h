@@ -2,7 +2,7 @@
 #pragma once
 #include "gemm_core.h"
 namespace hs {
-enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_STEM = 3 };   // STEM: 128x64 tile with BK = 32
+enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_STEM = 3, CFG_256x128 = 4 };   // STEM: 128x64 tile with BK = 32; 256x128: 8 waves, plain bf16 GEMMs only
 // combos: 0 (KC,KC) 1 (KC,RC) 2 (RC,RC) 3 (CONV,KC) 4 (DGRAD,WDGRAD) 5 (RC,CONV)
 int launch_bf16_plain(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s);
 int launch_bf16_conv(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s);
@@ -13,11 +13,11 @@ bool lds_attr_needed(const void* fn);   // true the first time a kernel pointer 
 
 // lds: dynamic LDS of this launch; max_lds: the most this kernel is ever launched with (set once as its limit)
 template <typename K>
-inline int launch_with_lds(K kernel, int lds, int max_lds, const GemmArgs& a, dim3 grid, hipStream_t s) {
+inline int launch_with_lds(K kernel, int lds, int max_lds, const GemmArgs& a, dim3 grid, hipStream_t s, int threads = 256) {
     if (max_lds >= 48 * 1024 && lds_attr_needed((const void*)kernel)) {
         HS_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     }
-    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, s, a);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }

@@ -62,6 +62,33 @@ def test_gemm_layouts(dtype, combo, shape):
             assert (out - ref).abs().max() <= _tol(dtype, K) * scale
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 4])       # 128x128, 128x64, 64x64, 256x128 (8 waves)
+@pytest.mark.parametrize("combo", ["nt", "nn", "tn"])
+def test_gemm_every_tile_config_exact(cfg, combo):
+    """each bf16 tile configuration forced on ragged and multi-tile shapes: integer data must come out exact"""
+    import ctypes as C
+    lib = L.lib()
+    lib.hs_gemm_debug.argtypes = [C.c_int32, C.c_int32]
+    try:
+        lib.hs_gemm_debug(cfg, 0)
+        for M, N, K in ((520, 264, 200), (256, 128, 64), (1000, 136, 1032), (72, 8, 40)):
+            if combo == "nt":
+                A, B = _rand((M, K), torch.bfloat16, True, 3), _rand((N, K), torch.bfloat16, True, 4)
+                ref, kinds = A.double() @ B.double().t(), (L.A_KC, L.B_KC, K, K)
+            elif combo == "nn":
+                A, B = _rand((M, K), torch.bfloat16, True, 3), _rand((K, N), torch.bfloat16, True, 4)
+                ref, kinds = A.double() @ B.double(), (L.A_KC, L.B_RC, K, N)
+            else:
+                A, B = _rand((K, M), torch.bfloat16, True, 3), _rand((K, N), torch.bfloat16, True, 4)
+                ref, kinds = A.double().t() @ B.double(), (L.A_RC, L.B_RC, M, N)
+            D = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+            bias = torch.arange(N, dtype=torch.float32, device=DEV)
+            raw.gemm(A.to(DEV), B.to(DEV), D, M, N, K, a_kind=kinds[0], b_kind=kinds[1], lda=kinds[2], ldb=kinds[3], bias=bias)
+            assert torch.equal(D.cpu().double(), ref + bias.cpu().double()), f"cfg {cfg} {combo} {(M, N, K)}"
+    finally:
+        lib.hs_gemm_debug(-1, 0)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_epilogue_and_splitk(dtype):
     M, N, K = 256, 192, 512

@@ -108,12 +108,12 @@ def main():
     shapes = [("nt", 4096, 2304, 768), ("nt", 4096, 768, 768), ("nt", 4096, 3072, 768), ("nt", 4096, 768, 3072),
               ("nn", 4096, 3072, 768), ("nn", 4096, 768, 3072), ("nn", 4096, 768, 2304),
               ("tn", 3072, 768, 4096), ("tn", 768, 3072, 4096), ("tn", 768, 768, 4096)]
-    print(f"{'shape':34s} " + " ".join(f"{c:>12s}" for c in ("auto", "128x128", "128x64", "64x64")) + ("   [plain n-fastest tile order @auto]" if ablate else ""))
+    print(f"{'shape':34s} " + " ".join(f"{c:>12s}" for c in ("auto", "128x128", "128x64", "64x64", "256x128")) + ("   [plain n-fastest tile order @auto]" if ablate else ""))
     for kind, M, N, K in shapes:
         fn = gemm_case(kind, M, N, K)
         fl = 2.0 * M * N * K
         row = []
-        for cfg in (-1, 0, 1, 2):
+        for cfg in (-1, 0, 1, 2, 4):
             lib.hs_gemm_debug(cfg, 0)
             row.append(fl / timeit(fn) / 1e12)
         extra = ""
@@ -125,6 +125,8 @@ def main():
             extra = "   " + " / ".join(f"{v:7.1f}" for v in ab)
         lib.hs_gemm_debug(-1, 0)
         print(f"{kind} M={M:6d} N={N:5d} K={K:6d}      " + " ".join(f"{v:9.1f} TF" for v in row) + extra)
+    if "--gemm-only" in sys.argv:
+        return
     convs = [("fwd", 32, 64, 56, 64, 3, 1), ("fwd", 32, 128, 28, 128, 3, 1), ("fwd", 32, 256, 14, 256, 3, 1), ("fwd", 32, 512, 7, 512, 3, 1),
              ("fwd", 32, 256, 56, 64, 1, 1), ("fwd", 32, 64, 56, 256, 1, 1), ("fwd", 32, 1024, 14, 256, 1, 1),
              ("dgrad", 32, 64, 56, 64, 3, 1), ("dgrad", 32, 256, 14, 256, 3, 1), ("dgrad", 32, 128, 56, 128, 3, 2),
