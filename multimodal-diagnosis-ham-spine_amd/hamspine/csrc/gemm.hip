@@ -89,8 +89,8 @@ int gemm_stat_rows(const hs_gemm_params* p) {
     if (!p || p->dtype != HS_BF16 || p->split_k > 1 || p->batch > 1) return 0;
     int cfg = (p->a_kind == HS_A_CONV && p->b_kind == HS_B_KC && p->g.C % 64 != 0) ? CFG_STEM : auto_cfg(p, true);
     if (g_dbg_cfg >= 0 && g_dbg_cfg <= CFG_64x64 && cfg != CFG_STEM) cfg = g_dbg_cfg;
-    if (g_dbg_cfg == CFG_256x128 && !(p->a_kind == HS_A_CONV || p->a_kind == HS_A_DGRAD || p->b_kind == HS_B_CONV)) cfg = CFG_256x128;
-    return ceil_div(p->M, cfg == CFG_64x64 ? 64 : cfg == CFG_256x128 ? 256 : 128);
+    if (g_dbg_cfg >= CFG_256x128 && g_dbg_cfg <= CFG_256x128x32 && !(p->a_kind == HS_A_CONV || p->a_kind == HS_A_DGRAD || p->b_kind == HS_B_CONV)) cfg = g_dbg_cfg;
+    return ceil_div(p->M, cfg == CFG_64x64 ? 64 : (cfg == CFG_256x128 || cfg == CFG_256x128x32) ? 256 : 128);
 }
 
 int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
@@ -238,14 +238,14 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     // intensity: 128x128 never wins, 128x64 wins once it yields >= ~1500 tiles, otherwise 64x64.
     if (cfg < 0) cfg = auto_cfg(p, vec);
     if (g_dbg_cfg >= 0 && g_dbg_cfg <= CFG_64x64 && cfg != CFG_STEM) cfg = g_dbg_cfg;
-    if (g_dbg_cfg == CFG_256x128 && bf16 && !conv) cfg = CFG_256x128;
+    if (g_dbg_cfg >= CFG_256x128 && g_dbg_cfg <= CFG_256x128x32 && bf16 && !conv) cfg = g_dbg_cfg;
     int BM = 64, BN = 64;
-    if (cfg == CFG_128x128) { BM = 128; BN = 128; }
-    else if (cfg == CFG_256x128) { BM = 256; BN = 128; }
+    if (cfg == CFG_128x128 || cfg == CFG_128x128x32) { BM = 128; BN = 128; }
+    else if (cfg == CFG_256x128 || cfg == CFG_256x128x32) { BM = 256; BN = 128; }
     else if (cfg == CFG_128x64 || cfg == CFG_STEM) { BM = 128; BN = 64; }
     a.tiles_m = ceil_div(p->M, BM);
     a.tiles_n = ceil_div(p->N, BN);
-    const int kb_cfg = cfg == CFG_STEM ? 32 : bk;
+    const int kb_cfg = (cfg == CFG_STEM || cfg == CFG_128x128x32 || cfg == CFG_256x128x32) ? 32 : bk;
     {
         // K tiles one workgroup walks -> LDS ring slots it needs (a single-tile 1x1 convolution allocates one slot, so
         // 5-6 workgroups instead of 2 share a CU and hide each other's load -> MFMA -> store latency chain)

@@ -7,6 +7,9 @@ namespace hs {
         case CFG_128x128: L(128, 128, 64, AK, BKD); \
         case CFG_128x64: L(128, 64, 64, AK, BKD);  \
         case CFG_64x64: L(64, 64, 64, AK, BKD);    \
+        case CFG_128x128x32: L(128, 128, 32, AK, BKD); \
+        case CFG_256x128x32:                       \
+            return launch_with_lds(gemm_bf16_kernel<256, 128, 32, AK, BKD, true, 4>, a.lds_stages * 384 * 32 * 2, 3 * 384 * 32 * 2, a, grid, s, 512); \
         case CFG_256x128:                          \
             return launch_with_lds(gemm_bf16_kernel<256, 128, 64, AK, BKD, true, 4>, a.lds_stages * 384 * 64 * 2, 3 * 384 * 64 * 2, a, grid, s, 512); \
     }                                              \

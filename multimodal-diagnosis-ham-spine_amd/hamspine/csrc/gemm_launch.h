@@ -2,7 +2,7 @@
 #pragma once
 #include "gemm_core.h"
 namespace hs {
-enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_STEM = 3, CFG_256x128 = 4 };   // STEM: 128x64 tile with BK = 32; 256x128: 8 waves, plain bf16 GEMMs only
+enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_STEM = 3, CFG_256x128 = 4, CFG_128x128x32 = 5, CFG_256x128x32 = 6 };   // STEM: 128x64 tile with BK = 32; 256x128: 8 waves, plain bf16 GEMMs only
 // combos: 0 (KC,KC) 1 (KC,RC) 2 (RC,RC) 3 (CONV,KC) 4 (DGRAD,WDGRAD) 5 (RC,CONV)
 int launch_bf16_plain(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s);
 int launch_bf16_conv(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s);

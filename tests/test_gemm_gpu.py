@@ -62,7 +62,7 @@ def test_gemm_layouts(dtype, combo, shape):
             assert (out - ref).abs().max() <= _tol(dtype, K) * scale
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 4])       # 128x128, 128x64, 64x64, 256x128 (8 waves)
+@pytest.mark.parametrize("cfg", [0, 1, 2, 4, 5, 6])   # 128x128, 128x64, 64x64, 256x128 (8 waves), 128x128x32, 256x128x32
 @pytest.mark.parametrize("combo", ["nt", "nn", "tn"])
 def test_gemm_every_tile_config_exact(cfg, combo):
     """each bf16 tile configuration forced on ragged and multi-tile shapes: integer data must come out exact"""

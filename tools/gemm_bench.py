@@ -108,12 +108,12 @@ def main():
     shapes = [("nt", 4096, 2304, 768), ("nt", 4096, 768, 768), ("nt", 4096, 3072, 768), ("nt", 4096, 768, 3072),
               ("nn", 4096, 3072, 768), ("nn", 4096, 768, 3072), ("nn", 4096, 768, 2304),
               ("tn", 3072, 768, 4096), ("tn", 768, 3072, 4096), ("tn", 768, 768, 4096)]
-    print(f"{'shape':34s} " + " ".join(f"{c:>12s}" for c in ("auto", "128x128", "128x64", "64x64", "256x128")) + ("   [plain n-fastest tile order @auto]" if ablate else ""))
+    print(f"{'shape':34s} " + " ".join(f"{c:>12s}" for c in ("auto", "128x128", "128x64", "64x64", "256x128", "128x128k32", "256x128k32")) + ("   [plain n-fastest tile order @auto]" if ablate else ""))
     for kind, M, N, K in shapes:
         fn = gemm_case(kind, M, N, K)
         fl = 2.0 * M * N * K
         row = []
-        for cfg in (-1, 0, 1, 2, 4):
+        for cfg in (-1, 0, 1, 2, 4, 5, 6):
             lib.hs_gemm_debug(cfg, 0)
             row.append(fl / timeit(fn) / 1e12)
         extra = ""
