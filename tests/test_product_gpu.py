@@ -759,3 +759,55 @@ def test_inference_folds_batchnorm_into_the_convolutions(mode):
     for name in ("conv1.weight", "layer1.0.conv1.weight", "layer4.2.bn3.weight", "fc.weight"):
         g = dict(p.named_parameters())[name].grad      # (the stem produces no image gradient by design)
         assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0, name
+
+
+def test_full_size_c2_size_independent_properties(tmp_path):
+    """BASELINE configs[1] at full size, properties that need no oracle:
+      * eval mode is row independent: the 32-row batch and its two 16-row halves give the same logits (folded
+        inference path; rows only meet inside BatchNorm, which uses running statistics here);
+      * the folded inference path and the autograd-capable eval path agree;
+      * gradients are linear in the loss: backward of 2*loss is exactly twice backward of loss wherever the kernels are
+        order-deterministic (a power-of-two scale commutes with every rounding), and within run-to-run spread elsewhere."""
+    import json as _json
+    import model as product_model
+    from hamspine import functional as F
+    from oracle.procedural import synthetic_batch
+    d = str(tmp_path / "bert_base")
+    os.makedirs(d)
+    with open(os.path.join(d, "config.json"), "w") as f:
+        _json.dump(dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                        intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2, hidden_act="gelu",
+                        hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, layer_norm_eps=1e-12), f)
+    os.environ["HAMSPINE_BERT_RANDOM_INIT"] = "1"
+    try:
+        torch.manual_seed(9)
+        net = product_model.MultimodalBaselineModel(num_classes=7, hidden_dim=256, dropout=0.0, pretrained_image=False,
+                                                    image_weights_path=None, text_model_name=d, num_heads=8,
+                                                    image_backbone="resnet50", classifier_type="mlp", fusion_type="basic")
+    finally:
+        os.environ.pop("HAMSPINE_BERT_RANDOM_INIT", None)
+    hamspine.set_compute_dtype("bf16")
+    net = net.to(DEV).eval()
+    images, ids, mask, labels = [t.to(DEV) for t in synthetic_batch(32, 224, 128, 30522, 7, seed=12, min_len=16)]
+    with torch.no_grad():
+        full = net(images, ids, mask)
+        halves = torch.cat([net(images[:16], ids[:16], mask[:16]), net(images[16:], ids[16:], mask[16:])], 0)
+    # the same rows land in different tiles of the same kernels: only split-K partitions of the weight-gradient-free
+    # forward could differ, and the forward has none -> bit-identical
+    assert torch.equal(full, halves), f"eval rows depend on the batch: {(full - halves).abs().max().item():.3e}"
+    with_graph = net(images, ids, mask)
+    _close(with_graph, full, "autograd eval path vs folded inference path", 2e-2, 2e-2)
+
+    net.train()
+    grads = []
+    for scale in (1.0, 2.0, 1.0):
+        net.zero_grad(set_to_none=True)
+        loss = F.cross_entropy(net.classifier(net.forward_features(images, ids, mask)), labels, label_smoothing=0.02)
+        (loss * scale).backward()
+        grads.append({k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+    worst = 0.0
+    for k, g1 in grads[0].items():
+        spread = (g1 - grads[2][k]).abs().max().item()                      # run-to-run (float atomics), usually 0
+        err = (grads[1][k] - 2.0 * g1).abs().max().item()
+        assert err <= 4 * spread + 1e-6 * g1.abs().max().item(), f"{k}: |g(2L) - 2 g(L)| = {err:.3e}, run-to-run {spread:.3e}"
+        worst = max(worst, err)

@@ -10,8 +10,9 @@ def main(path, nsteps):
     n = len(rows)
     per = n // nsteps
     # use the last full step-sized window of launches that sits inside the steady state: take rows of the last 3 steps
-    lo = n - 3 * per
-    rows = rows[lo:]
+    skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0     # steps to leave out at the end (bench.py's roofline leg: 3)
+    lo = n - (3 + skip) * per
+    rows = rows[lo:lo + 3 * per]
     t0, t1 = rows[0][0], max(r[1] for r in rows)
     wall = (t1 - t0) / 1e6
     busy = 0.0
