@@ -615,28 +615,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
     for (int k = threadIdx.x; k < NP * H; k += 256) ws[(long long)blockIdx.x * NP * H + k] = ln_sh[k];
 }
+template <int CW>
 __global__ __launch_bounds__(256) void ln_bwd_final_kernel(const float* __restrict__ ws, int nw, int H, int np,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            float* __restrict__ dbias) {
-    // block = 64 columns x 4 row groups: coalesced 256-byte row segments, 4 partial sums merged through LDS;
+    // block = CW columns x RG = 256/CW row groups; the RG partial sums are merged through LDS in a fixed order.
+    // CW = 16 gives H/16 workgroups (48 for BERT-base instead of 12 at CW = 64: the 1.5 MB of partials of a 4096-row
+    // call were read by 12 CUs) with 64-byte row segments.
     // partial row w holds np (2 or 3) vectors of H floats: dgamma, dbeta(, bias gradient of the preceding layer)
-    __shared__ float sh[3][4][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    constexpr int RG = 256 / CW;
+    __shared__ float sh[3][RG][CW];
+    const int cl = threadIdx.x % CW, rg = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + cl;
     float acc[3] = {0.f, 0.f, 0.f};
     if (c < H) {
         int w = rg;
-        for (; w + 12 < nw; w += 16) {   // 4 independent loads in flight per accumulator
+        for (; w + 3 * RG < nw; w += 4 * RG) {   // 4 independent loads in flight per accumulator
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 if (k < np) {
-                    const float v0 = ws[((long long)w * np + k) * H + c], v1 = ws[((long long)(w + 4) * np + k) * H + c];
-                    const float v2 = ws[((long long)(w + 8) * np + k) * H + c], v3 = ws[((long long)(w + 12) * np + k) * H + c];
+                    const float v0 = ws[((long long)w * np + k) * H + c], v1 = ws[((long long)(w + RG) * np + k) * H + c];
+                    const float v2 = ws[((long long)(w + 2 * RG) * np + k) * H + c];
+                    const float v3 = ws[((long long)(w + 3 * RG) * np + k) * H + c];
                     acc[k] += (v0 + v1) + (v2 + v3);
                 }
             }
         }
-        for (; w < nw; w += 4)
+        for (; w < nw; w += RG)
 #pragma unroll
             for (int k = 0; k < 3; ++k)
                 if (k < np) acc[k] += ws[((long long)w * np + k) * H + c];
@@ -644,10 +649,13 @@ __global__ __launch_bounds__(256) void ln_bwd_final_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < 3; ++k) sh[k][rg][cl] = acc[k];
     __syncthreads();
-    if (rg == 0 && c < H) {
-        dgamma[c] = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
-        dbeta[c] = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
-        if (np > 2 && dbias) dbias[c] = (sh[2][0][cl] + sh[2][1][cl]) + (sh[2][2][cl] + sh[2][3][cl]);
+    if (rg < 3 && rg < np && c < H) {             // row group k merges vector k
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < RG; ++r) t += sh[rg][r][cl];
+        if (rg == 0) dgamma[c] = t;
+        else if (rg == 1) dbeta[c] = t;
+        else if (dbias) dbias[c] = t;
     }
 }
 
@@ -703,7 +711,7 @@ static int ln_bwd_t(const void* dy, const void* x, const float* gamma, const flo
     }
 #undef LN_BWD
     HS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3(ceil_div(H, 64)), dim3(256), 0, s, ws, blocks, H, np, dgamma, dbeta, dbias);
+    hipLaunchKernelGGL(ln_bwd_final_kernel<16>, dim3(ceil_div(H, 16)), dim3(256), 0, s, ws, blocks, H, np, dgamma, dbeta, dbias);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
