@@ -115,6 +115,12 @@ typedef struct hs_gemm_params {
        BatchNorm, written as (count, mean, M2) triples to colstats[(tile_row * N + n) * 3 ...]; hs_gemm_stat_rows(p) gives
        the number of tile rows.  Saves BatchNorm's own pass over the convolution output (hs_bn_params.partial_rows). */
     float* colstats;
+    /* optional (bf16, a_kind = HS_A_RC, no split-K, batch 1): rowsum_a[m] = sum over k of A[k][m] in f32 -- with A = dY this
+       is the bias gradient of the Linear whose weight gradient the GEMM computes, so db costs one extra MFMA per A
+       fragment in the first tile column instead of a column-sum pass over dY.  With seg_rows the sums of segment i go to
+       rowsum_seg[i-1] (row index rebased), like D_seg. */
+    float* rowsum_a;
+    float* rowsum_seg[2];
 } hs_gemm_params;
 
 hs_status hs_gemm(const hs_gemm_params* p, void* stream);

@@ -52,6 +52,7 @@ class GemmParams(C.Structure):
         ("mul_mode", i32), ("mul_src", vp), ("ldm", i32),
         ("accumulate", i32),
         ("seg_rows", i32), ("D_seg", vp * 2), ("colscale", vp), ("residual_before_act", i32), ("colstats", vp),
+        ("rowsum_a", vp), ("rowsum_seg", vp * 2),
     ]
 
 

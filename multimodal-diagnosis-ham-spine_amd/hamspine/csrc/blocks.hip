@@ -353,7 +353,19 @@ static int linear_fwd_run(Run& r, const void* x, long long M, int ldx, const hs_
     return HS_OK;
 }
 // parameter gradients: dw = dy^T x, db = colsum(dy)
+static bool fused_bias_grad_enabled() {     // HAMSPINE_FUSED_BIAS_GRAD=0: bias gradients by separate column-sum passes
+    static const bool on = [] {
+        const char* e = getenv("HAMSPINE_FUSED_BIAS_GRAD");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+// a weight-gradient GEMM (bf16, unsplit) can produce the bias gradient as the row sums of its A operand
+static bool bias_in_wgrad(int dt, int out_f, int in_f, long long M) {
+    return dt == HS_BF16 && fused_bias_grad_enabled() && hs_gemm_suggest_split(out_f, in_f, (int)M, dt) <= 1;
+}
 static int linear_wgrad_run(Run& r, const void* x, long long M, int ldx, const hs_linear& lin, const void* dy, int ldy) {
+    bool db_done = false;
     if (lin.dw) {
         hs_gemm_params p = gemm_defaults(r.dt);
         p.a_kind = HS_A_RC; p.b_kind = HS_B_RC;
@@ -363,9 +375,13 @@ static int linear_wgrad_run(Run& r, const void* x, long long M, int ldx, const h
         p.b_elems = (M - 1) * ldx + lin.in_f;
         p.lda = ldy; p.ldb = ldx;
         p.D = lin.dw; p.ldd = lin.in_f; p.out_dtype = HS_F32;
+        if (lin.db && bias_in_wgrad(r.dt, lin.out_f, lin.in_f, M)) {
+            p.rowsum_a = lin.db;
+            db_done = true;
+        }
         HS_PROPAGATE(gemm_splitk(r, p));
     }
-    if (lin.db) {
+    if (lin.db && !db_done) {
         const long long mk = r.ws.mark();
         const long long wsb = hs_colsum_ws_bytes(M, lin.out_f);
         void* w = r.ws.alloc(wsb);
@@ -1053,7 +1069,14 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
             p.seg_rows = Hd;
             p.D_seg[0] = d.k.dw;
             p.D_seg[1] = d.v.dw;
+            const bool bias_too = d.q.db && d.k.db && d.v.db && bias_in_wgrad(r.dt, 3 * Hd, Hd, M);
+            if (bias_too) {
+                p.rowsum_a = d.q.db;
+                p.rowsum_seg[0] = d.k.db;
+                p.rowsum_seg[1] = d.v.db;
+            }
             HS_PROPAGATE(gemm_splitk(r, p));
+            if (bias_too) return HS_OK;
         }
         const hs_linear* lins[3] = {&d.q, &d.k, &d.v};
         for (int i = 0; i < 3; ++i) {

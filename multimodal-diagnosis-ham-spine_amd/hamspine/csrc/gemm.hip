@@ -148,6 +148,15 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     a.colstats = p->colstats;
     a.colscale = p->colscale;
     a.res_pre_act = p->residual_before_act;
+    a.rowsum[0] = p->rowsum_a;
+    a.rowsum[1] = p->rowsum_seg[0];
+    a.rowsum[2] = p->rowsum_seg[1];
+    if (p->rowsum_a) {
+        HS_REQUIRE(p->dtype == HS_BF16 && p->a_kind == HS_A_RC && p->split_k <= 1 && batch == 1,
+                   "hs_gemm: rowsum_a needs bf16, a row-contiguous A, no split-K and no batch");
+        HS_REQUIRE(p->seg_rows <= 0 || (p->rowsum_seg[0] && (p->M <= 2 * p->seg_rows || p->rowsum_seg[1])),
+                   "hs_gemm: rowsum_a with seg_rows needs rowsum_seg");
+    }
     a.seg_rows = p->seg_rows;
     a.D_seg[0] = (char*)p->D_seg[0];
     a.D_seg[1] = (char*)p->D_seg[1];

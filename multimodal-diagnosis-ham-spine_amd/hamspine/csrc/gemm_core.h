@@ -64,6 +64,7 @@ struct GemmArgs {
     int vec_store;             // 1: N%4==0 and all row strides/bases allow 4-wide accesses
     int seg_rows;              // >0: output rows are split over D / D_seg[0] / D_seg[1]
     char* D_seg[2];
+    float* rowsum[3];          // optional (row-contiguous A): rowsum[seg][m] = sum_k A[k][m], the bias gradient of a wgrad GEMM
 };
 
 // parity-major row order of a stride-2 dgrad: permuted row m -> (image, input pixel)
@@ -556,6 +557,15 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias gradient of a weight-gradient GEMM (A = dY stored [k][m]): the column sums of dY are one more output column,
+    // dY^T . 1 -- the waves of the first tile column feed their A fragments to one extra MFMA against a fragment of ones.
+    f32x4 accb[A_RC ? FM : 1];
+    bool do_rowsum = false;
+    if constexpr (A_RC) {
+        do_rowsum = a.rowsum[0] != nullptr && tn == 0 && wn == 0;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // 3-slot LDS ring, software pipelined at two levels.
     //  * tiles: when the waves meet at the barrier of tile t, tile t+1 has landed, tile t+2 is in flight and the
@@ -641,6 +651,14 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
 #pragma unroll
             for (int j = 0; j < FN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        if constexpr (A_RC) {
+            if (do_rowsum) {
+                const s16x4 o4 = {0x3f80, 0x3f80, 0x3f80, 0x3f80};      // bf16 1.0
+                const bf16x8 ones = __builtin_bit_cast(bf16x8, __builtin_shufflevector(o4, o4, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int i = 0; i < FM; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+            }
+        }
     };
 
     int cur = 0;   // slot of tile t
@@ -744,6 +762,18 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
     }
 
     // ---- epilogue: lane owns m = .. + l15, n = .. + 4g + {0..3} ---------------------------------
+    if constexpr (A_RC) {
+        if (do_rowsum && g == 0) {           // every n of the ones-operand holds the same sum: lanes 0..15 write one row each
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * WM + i * 16 + l15;
+                if (m < a.M) {
+                    const int seg = a.seg_rows > 0 ? m / a.seg_rows : 0;
+                    a.rowsum[seg][m - seg * (a.seg_rows > 0 ? a.seg_rows : 0)] = accb[i][0];
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * WM + i * 16 + l15;

@@ -48,9 +48,9 @@ def conv_geom(N, H, W, Cin, Kout, R, S, stride, pad, row_pitch=None, img_pitch=N
 def gemm(A, B, D, M, N, K, a_kind=L.A_KC, b_kind=L.B_KC, lda=0, ldb=0, ldd=None, geom=None,
          batch=1, batch_inner=1, a_bs=(0, 0), b_bs=(0, 0), d_bs=(0, 0), split_k=1,
          alpha=1.0, bias=None, act=L.ACT_NONE, preact=None, residual=None, ldr=None,
-         dropout_p=0.0, dropout_seed=0, mul_mode=L.MUL_NONE, mul_src=None, ldm=None, accumulate=False):
+         dropout_p=0.0, dropout_seed=0, mul_mode=L.MUL_NONE, mul_src=None, ldm=None, accumulate=False, rowsum_a=None):
     """D[m][n] = epi(alpha * sum_k A(m,k) B(n,k)); see include/hamspine.h for the operand kinds."""
-    need_gpu(A, B, D, bias, preact, residual, mul_src)
+    need_gpu(A, B, D, bias, preact, residual, mul_src, rowsum_a)
     p = L.GemmParams()
     p.dtype = hs_dtype(A)
     if hs_dtype(B) != p.dtype:
@@ -88,6 +88,7 @@ def gemm(A, B, D, M, N, K, a_kind=L.A_KC, b_kind=L.B_KC, lda=0, ldb=0, ldd=None,
     p.mul_src = ptr(mul_src)
     p.ldm = p.ldd if ldm is None else ldm
     p.accumulate = 1 if accumulate else 0
+    p.rowsum_a = ptr(rowsum_a)
     L.check(L.lib().hs_gemm(C.byref(p), stream_ptr()), "hs_gemm")
     return D
 

@@ -89,6 +89,31 @@ def test_gemm_every_tile_config_exact(cfg, combo):
         lib.hs_gemm_debug(-1, 0)
 
 
+@pytest.mark.parametrize("cfg", [-1, 1, 2])
+def test_wgrad_gemm_row_sums_are_the_bias_gradient(cfg):
+    """rowsum_a: the weight-gradient GEMM dY^T X also returns colsum(dY) (one extra MFMA per A fragment in the first tile
+    column).  Integer data: exact, on ragged sizes, several tile configurations and a strided dY (ld > out features)."""
+    import ctypes as C
+    lib = L.lib()
+    lib.hs_gemm_debug.argtypes = [C.c_int32, C.c_int32]
+    try:
+        lib.hs_gemm_debug(cfg, 0)
+        for rows, out_f, in_f, ld in ((300, 72, 40, 72), (4096, 768, 768, 768), (130, 200, 264, 208), (64, 8, 8, 24)):
+            dY = _rand((rows, ld), torch.bfloat16, True, 5)
+            X = _rand((rows, in_f), torch.bfloat16, True, 6)
+            dW = torch.full((out_f, in_f), float("nan"), dtype=torch.float32, device=DEV)
+            db = torch.full((out_f,), float("nan"), dtype=torch.float32, device=DEV)
+            raw.gemm(dY.to(DEV), X.to(DEV), dW, out_f, in_f, rows, a_kind=L.A_RC, b_kind=L.B_RC, lda=ld, ldb=in_f, rowsum_a=db)
+            assert torch.equal(dW.cpu().double(), dY[:, :out_f].double().t() @ X.double()), (cfg, rows, out_f, in_f)
+            assert torch.equal(db.cpu().double(), dY[:, :out_f].double().sum(0)), (cfg, rows, out_f, in_f)
+    finally:
+        lib.hs_gemm_debug(-1, 0)
+    with pytest.raises(L.HamspineError, match="rowsum_a"):
+        A = _rand((64, 64), torch.bfloat16, True, 1).to(DEV)
+        raw.gemm(A, A, torch.empty(64, 64, device=DEV), 64, 64, 64, a_kind=L.A_KC, b_kind=L.B_KC, lda=64, ldb=64,
+                 rowsum_a=torch.empty(64, device=DEV))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_epilogue_and_splitk(dtype):
     M, N, K = 256, 192, 512
