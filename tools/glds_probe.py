@@ -1,3 +1,4 @@
+"""Runs tools/probe.so (see tools/probe.hip): prints what LDS-DMA wrote for in-range and out-of-range source offsets."""
 import ctypes, torch, os
 lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe.so"))
 src = torch.arange(1, 257, dtype=torch.int32, device="cuda")

@@ -1,3 +1,6 @@
+// Probe behind a claim the GEMM core relies on (csrc/gemm_core.h): a `buffer_load ... lds` (LDS-DMA) whose source offset is
+// beyond the buffer resource's num_records writes ZEROS to its LDS slot (it does not skip the write).  Build:
+//   hipcc --offload-arch=gfx950 -shared -fPIC -o tools/probe.so tools/probe.hip ; run tools/glds_probe.py on the GPU box.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
