@@ -136,6 +136,9 @@ int32_t hs_gemm_suggest_split(int32_t M, int32_t N, int32_t K, int32_t dtype);
 /* measurement only: force a tile configuration (0 128x128, 1 128x64, 2 64x64, -1 auto) and ablation bits
    (16 = plain n-fastest tile order instead of the L2-grouped one; results stay correct). */
 void hs_gemm_debug(int32_t cfg_override, int32_t ablate);
+/* measurement only: while device_buffer is not NULL every bf16 hs_gemm launch writes 6 shader-clock stamps per workgroup
+   (start, first DMA issued, first K tile landed, K loop done, epilogue done, unused) to it; size it 48 bytes x workgroups. */
+void hs_gemm_debug_stamps(void* device_buffer);
 void hs_prof_enable(int32_t on);
 hs_status hs_prof_collect(double* flops, double* ms, int64_t* launches);
 /* measurement only: append one CSV line per recorded launch (class, operand combo, tile cfg, M, N, K, batch, split_k,

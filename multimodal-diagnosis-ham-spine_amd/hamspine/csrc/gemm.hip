@@ -4,6 +4,7 @@
 #include <vector>
 #include <stdarg.h>
 #include <math.h>
+#include <map>
 #include "gemm_launch.h"
 
 namespace hs {
@@ -63,6 +64,7 @@ static void prof_end(hipStream_t s, ProfRec& r) {
 __global__ void null_kernel() {}
 
 static int g_dbg_cfg = -1, g_dbg_ablate = 0;   // measurement overrides (hs_gemm_debug)
+static unsigned long long* g_dbg_stamps = nullptr;   // hs_gemm_debug_stamps: per-workgroup clock stamps of the next launches
 
 static int combo_of(int ak, int bk) {
     if (ak == HS_A_KC && bk == HS_B_KC) return 0;
@@ -148,6 +150,7 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     a.colstats = p->colstats;
     a.colscale = p->colscale;
     a.res_pre_act = p->residual_before_act;
+    a.stamps = g_dbg_stamps;
     a.rowsum[0] = p->rowsum_a;
     a.rowsum[1] = p->rowsum_seg[0];
     a.rowsum[2] = p->rowsum_seg[1];
@@ -280,6 +283,38 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
         a.splitk_ws = p->splitk_ws;
     }
     if (a.colstats) HS_REQUIRE(bf16 && split == 1 && batch == 1, "hs_gemm: colstats needs bf16 operands, no split-K, no batch");
+    {   // measurement aid (HAMSPINE_EPI_HIST=1): which epilogue feature sets the launches use, printed at exit
+        static const bool hist = [] { const char* e = getenv("HAMSPINE_EPI_HIST"); return e && e[0] == '1'; }();
+        if (hist) {
+            static std::mutex mu;
+            static std::map<std::pair<unsigned, int>, long long> cnt;
+            static const bool reg = [] {
+                atexit([] {
+                    for (auto& kv : cnt) fprintf(stderr, "[epi] flags 0x%05x bf16 %d : %lld launches\n", kv.first.first, kv.first.second, kv.second);
+                });
+                return true;
+            }();
+            (void)reg;
+            unsigned f = 0;
+            if (p->bias) f |= EPI_BIAS;
+            if (p->colscale) f |= EPI_COLSCALE;
+            if (p->mul_mode == HS_MUL_GELU_GRAD) f |= EPI_MUL_GELU;
+            else if (p->mul_mode != HS_MUL_NONE) f |= EPI_MUL_RELU;
+            if (p->seg_rows > 0) f |= EPI_SEG;
+            if (p->D_preact) f |= EPI_PREACT;
+            if (p->residual) f |= p->residual_before_act ? EPI_RES_PRE : EPI_RES_POST;
+            if (p->act == HS_ACT_RELU) f |= EPI_RELU;
+            else if (p->act == HS_ACT_GELU) f |= EPI_GELU;
+            if (p->dropout_p > 0.f) f |= EPI_DROP;
+            if (p->out_dtype == HS_F32) f |= EPI_OUT_F32;
+            if (p->accumulate) f |= EPI_ACCUM;
+            if (a.vec_store) f |= EPI_VEC;
+            if (a.parity) f |= EPI_PARITY;
+            if (split > 1) f |= 0x80000;
+            std::lock_guard<std::mutex> lk(mu);
+            cnt[{f, p->dtype == HS_BF16 ? 1 : 0}]++;
+        }
+    }
     dim3 grid(a.tiles_m * a.tiles_n, 1, split > 1 ? split : batch);
     int st;
     ProfRec rec;
@@ -314,6 +349,8 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
 }  // namespace hs
 
 extern "C" {
+/* measurement only: device buffer of 6 x (workgroups of the largest launch) uint64, or NULL to switch the stamps off */
+void hs_gemm_debug_stamps(void* device_buffer) { hs::g_dbg_stamps = (unsigned long long*)device_buffer; }
 void hs_gemm_debug(int32_t cfg_override, int32_t ablate) {
     hs::g_dbg_cfg = cfg_override;
     hs::g_dbg_ablate = ablate;

@@ -16,6 +16,7 @@
 // MFMA operand roles are swapped (MFMA-A := B tile, MFMA-B := A tile) so that each lane ends up with
 // 4 consecutive n for one m: the epilogue then issues 8/16-byte row-contiguous accesses.
 #pragma once
+#include <type_traits>
 #include "hs_common.h"
 
 namespace hs {
@@ -65,7 +66,15 @@ struct GemmArgs {
     int seg_rows;              // >0: output rows are split over D / D_seg[0] / D_seg[1]
     char* D_seg[2];
     float* rowsum[3];          // optional (row-contiguous A): rowsum[seg][m] = sum_k A[k][m], the bias gradient of a wgrad GEMM
+    unsigned long long* stamps;   // measurement only (hs_gemm_debug_stamps): 6 shader-clock stamps per workgroup, else NULL
 };
+// stamp k of this workgroup: 0 start, 1 first DMA issued, 2 first tile landed (barrier passed), 3 K loop done,
+// 4 epilogue done (stores issued); slot 5 = XCC/CU id bits of HW_ID
+#define HS_STAMP(k)                                                                                              \
+    do {                                                                                                         \
+        if (a.stamps && threadIdx.x == 0)                                                                        \
+            a.stamps[((long long)blockIdx.z * gridDim.x + blockIdx.x) * 6 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
 
 // parity-major row order of a stride-2 dgrad: permuted row m -> (image, input pixel)
 __device__ __forceinline__ int parity_class(const GemmArgs& a, int m) {
@@ -90,15 +99,18 @@ __device__ __forceinline__ long long parity_row(const GemmArgs& a, int m) {   //
 // ------------------------------------------------------------------------------------------------
 // epilogue for 4 consecutive n of one row m.  TIn = element type of mul_src; TOut chosen at run time.
 // ------------------------------------------------------------------------------------------------
+// Epilogue operands are device-global memory; the pointers come out of pin_sgpr() as opaque values, so the address space
+// is stated explicitly (otherwise every access becomes a flat_ instruction).
+#define HS_GLOBAL __attribute__((address_space(1)))
 template <typename T>
 __device__ __forceinline__ void load4(const char* base, long long idx, bool vec, int nvalid, float* f) {
-    const T* p = (const T*)base + idx;
+    const HS_GLOBAL T* p = (const HS_GLOBAL T*)((const T*)base + idx);
     if (vec) {
         if constexpr (sizeof(T) == 4) {
-            f32x4 v = *(const f32x4*)p;
+            f32x4 v = *(const HS_GLOBAL f32x4*)p;
             f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
         } else {
-            u32x2 v = *(const u32x2*)p;
+            u32x2 v = *(const HS_GLOBAL u32x2*)p;
             f[0] = __uint_as_float(v[0] << 16);
             f[1] = __uint_as_float(v[0] & 0xffff0000u);
             f[2] = __uint_as_float(v[1] << 16);
@@ -111,14 +123,14 @@ __device__ __forceinline__ void load4(const char* base, long long idx, bool vec,
 }
 template <typename T>
 __device__ __forceinline__ void store4(char* base, long long idx, bool vec, int nvalid, const float* f) {
-    T* p = (T*)base + idx;
+    HS_GLOBAL T* p = (HS_GLOBAL T*)((T*)base + idx);
     if (vec) {
         if constexpr (sizeof(T) == 4) {
             f32x4 v = {f[0], f[1], f[2], f[3]};
-            *(f32x4*)p = v;
+            *(HS_GLOBAL f32x4*)p = v;
         } else {
             bf16x4 v = {(bf16_t)f[0], (bf16_t)f[1], (bf16_t)f[2], (bf16_t)f[3]};
-            *(bf16x4*)p = v;
+            *(HS_GLOBAL bf16x4*)p = v;
         }
     } else {
 #pragma unroll
@@ -127,28 +139,100 @@ __device__ __forceinline__ void store4(char* base, long long idx, bool vec, int 
     }
 }
 
-template <typename T>
-__device__ __forceinline__ void epilogue4(const GemmArgs& a, long long dbase, int z, int m, int n, float* v) {
-    if (m >= a.M || n >= a.N) return;
-    const long long mr = a.parity ? parity_row(a, m) : (long long)m;   // row of D / residual / multiplier source
-    const int nvalid = min(4, a.N - n);
-    const bool vec = a.vec_store && nvalid == 4;
+// Everything the epilogue reads from the kernel arguments, fetched ONCE per workgroup.  The arguments live in the kernarg
+// segment; read where they are used, each of the ~12 feature tests of every output fragment became an `s_load` +
+// `s_waitcnt lgkmcnt(0)` (the register allocator prefers re-loading to keeping: 44 scalar loads after the last MFMA),
+// which made the epilogue of a 128x64 tile 5.7 us of an 13 us workgroup lifetime (tools/gemm_stamps.py).  Here the
+// features are folded into one bit mask and the values are pinned into registers (the empty asm makes them opaque,
+// so they cannot be rematerialised from memory).
+enum {
+    EPI_BIAS = 1, EPI_COLSCALE = 2, EPI_MUL_GELU = 4, EPI_MUL_RELU = 8, EPI_SEG = 16, EPI_PREACT = 32, EPI_RES_PRE = 64,
+    EPI_RES_POST = 128, EPI_RELU = 256, EPI_GELU = 512, EPI_DROP = 1024, EPI_OUT_F32 = 2048, EPI_ACCUM = 4096, EPI_VEC = 8192,
+    EPI_PARITY = 16384
+};
+struct Epi {
+    unsigned flags;
+    int M, N, ldd, ldr, ldm, seg_rows;
+    float alpha, drop_inv_keep;
+    unsigned drop_thresh;
+    unsigned long long drop_seed;
+    const float* bias;
+    const float* colscale;
+    const char* mul_src;
+    const char* residual;
+    char* D;
+    char* D_seg0;
+    char* D_seg1;
+    char* D_preact;
+};
+template <typename V>
+__device__ __forceinline__ void pin_sgpr(V& v) {
+    asm volatile("" : "+s"(v));
+}
+__device__ __forceinline__ Epi make_epi(const GemmArgs& a) {
+    Epi e;
+    unsigned f = 0;
+    if (a.bias) f |= EPI_BIAS;
+    if (a.colscale) f |= EPI_COLSCALE;
+    if (a.mul_mode == HS_MUL_GELU_GRAD) f |= EPI_MUL_GELU;
+    else if (a.mul_mode != HS_MUL_NONE) f |= EPI_MUL_RELU;
+    if (a.seg_rows > 0) f |= EPI_SEG;
+    if (a.D_preact) f |= EPI_PREACT;
+    if (a.residual) f |= a.res_pre_act ? EPI_RES_PRE : EPI_RES_POST;
+    if (a.act == HS_ACT_RELU) f |= EPI_RELU;
+    else if (a.act == HS_ACT_GELU) f |= EPI_GELU;
+    if (a.drop_thresh) f |= EPI_DROP;
+    if (a.out_f32) f |= EPI_OUT_F32;
+    if (a.accumulate) f |= EPI_ACCUM;
+    if (a.vec_store) f |= EPI_VEC;
+    if (a.parity) f |= EPI_PARITY;
+    e.flags = f;
+    e.M = a.M; e.N = a.N; e.ldd = a.ldd; e.ldr = a.ldr; e.ldm = a.ldm; e.seg_rows = a.seg_rows;
+    e.alpha = a.alpha; e.drop_inv_keep = a.drop_inv_keep;
+    e.drop_thresh = a.drop_thresh; e.drop_seed = a.drop_seed;
+    e.bias = a.bias; e.colscale = a.colscale; e.mul_src = a.mul_src; e.residual = a.residual;
+    e.D = a.D; e.D_seg0 = a.D_seg[0]; e.D_seg1 = a.D_seg[1]; e.D_preact = a.D_preact;
+    pin_sgpr(e.flags);
+    pin_sgpr(e.M); pin_sgpr(e.N); pin_sgpr(e.ldd); pin_sgpr(e.ldr); pin_sgpr(e.ldm); pin_sgpr(e.seg_rows);
+    unsigned al = __float_as_uint(e.alpha), ik = __float_as_uint(e.drop_inv_keep);
+    pin_sgpr(al); pin_sgpr(ik);
+    e.alpha = __uint_as_float(al); e.drop_inv_keep = __uint_as_float(ik);
+    pin_sgpr(e.drop_thresh); pin_sgpr(e.drop_seed);
+    pin_sgpr(e.bias); pin_sgpr(e.colscale); pin_sgpr(e.mul_src); pin_sgpr(e.residual);
+    pin_sgpr(e.D); pin_sgpr(e.D_seg0); pin_sgpr(e.D_seg1); pin_sgpr(e.D_preact);
+    return e;
+}
+
+// CF >= 0: the feature set is a compile-time constant (straight-line code for the combinations the training step uses, see
+// the dispatch in the kernel); CF < 0: tested at run time.  FULL: the tile lies inside the matrix and rows are 4-wide
+// storable, so no lane needs bounds or tail handling.  The fully generic body is ~650 instructions of branches per fragment
+// (x8-16 fragments: > 40 KB of code walked sparsely), which is what made the epilogue as long as the K loop.
+template <typename T, int CF = -1, bool FULL = false>
+__device__ __forceinline__ void epilogue4(const GemmArgs& a, const Epi& e, long long dbase, int z, int m, int n, float* v) {
+    if constexpr (!FULL) {
+        if (m >= e.M || n >= e.N) return;
+    }
+    const unsigned fl = CF >= 0 ? (unsigned)CF : e.flags;
+    const long long mr = (fl & EPI_PARITY) ? parity_row(a, m) : (long long)m;   // row of D / residual / multiplier source
+    const int nvalid = FULL ? 4 : min(4, e.N - n);
+    const bool vec = FULL ? true : ((fl & EPI_VEC) && nvalid == 4);
+    const bool out_f32 = fl & EPI_OUT_F32;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] *= a.alpha;
-    if (a.colscale) {
+    for (int j = 0; j < 4; ++j) v[j] *= e.alpha;
+    if (fl & EPI_COLSCALE) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (j < nvalid) v[j] *= a.colscale[n + j];
+            if (j < nvalid) v[j] *= ((const HS_GLOBAL float*)e.colscale)[n + j];
     }
-    if (a.bias) {
+    if (fl & EPI_BIAS) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (j < nvalid) v[j] += a.bias[n + j];
+            if (j < nvalid) v[j] += ((const HS_GLOBAL float*)e.bias)[n + j];
     }
-    if (a.mul_mode != HS_MUL_NONE) {
+    if (fl & (EPI_MUL_GELU | EPI_MUL_RELU)) {
         float u[4];
-        load4<T>(a.mul_src, mr * a.ldm + n, vec, nvalid, u);   // mul_src is never batched
-        if (a.mul_mode == HS_MUL_GELU_GRAD) {
+        load4<T>(e.mul_src, mr * e.ldm + n, vec, nvalid, u);   // mul_src is never batched
+        if (fl & EPI_MUL_GELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] *= gelu_grad_t<T>(u[j]);
         } else {
@@ -156,54 +240,54 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, long long dbase, in
             for (int j = 0; j < 4; ++j) v[j] = u[j] > 0.f ? v[j] : 0.f;
         }
     }
-    char* Dp = a.D;
-    long long didx = dbase + mr * a.ldd + n;
-    if (a.seg_rows > 0) {
-        const int seg = m / a.seg_rows;
-        if (seg > 0) Dp = a.D_seg[seg - 1];
-        didx = (long long)(m - seg * a.seg_rows) * a.ldd + n;
+    char* Dp = e.D;
+    long long didx = dbase + mr * e.ldd + n;
+    if (fl & EPI_SEG) {
+        const int seg = m / e.seg_rows;
+        if (seg > 0) Dp = seg == 1 ? e.D_seg0 : e.D_seg1;
+        didx = (long long)(m - seg * e.seg_rows) * e.ldd + n;
     }
-    if (a.D_preact) {
-        if (a.out_f32) store4<float>(a.D_preact, didx, vec, nvalid, v);
-        else store4<T>(a.D_preact, didx, vec, nvalid, v);
+    if (fl & EPI_PREACT) {
+        if (out_f32) store4<float>(e.D_preact, didx, vec, nvalid, v);
+        else store4<T>(e.D_preact, didx, vec, nvalid, v);
     }
-    if (a.residual && a.res_pre_act) {
+    if (fl & EPI_RES_PRE) {
         float r[4];
-        const long long ridx = dbase + mr * a.ldr + n;
-        if (a.out_f32) load4<float>(a.residual, ridx, vec, nvalid, r);
-        else load4<T>(a.residual, ridx, vec, nvalid, r);
+        const long long ridx = dbase + mr * e.ldr + n;
+        if (out_f32) load4<float>(e.residual, ridx, vec, nvalid, r);
+        else load4<T>(e.residual, ridx, vec, nvalid, r);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += r[j];
     }
-    if (a.act == HS_ACT_RELU) {
+    if (fl & EPI_RELU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-    } else if (a.act == HS_ACT_GELU) {
+    } else if (fl & EPI_GELU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = gelu_fwd_t<T>(v[j]);
     }
-    if (a.drop_thresh) {
-        const unsigned long long e = ((unsigned long long)z * a.M + m) * (unsigned long long)a.N + n;
-        if ((e & 3) == 0) {
+    if (fl & EPI_DROP) {
+        const unsigned long long q = ((unsigned long long)z * e.M + m) * (unsigned long long)e.N + n;
+        if ((q & 3) == 0) {
             float sc[4];
-            dropout_scale4(a.drop_seed, e, a.drop_thresh, a.drop_inv_keep, sc);
+            dropout_scale4(e.drop_seed, q, e.drop_thresh, e.drop_inv_keep, sc);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] *= sc[j];
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= dropout_scale(a.drop_seed, e + j, a.drop_thresh, a.drop_inv_keep);
+            for (int j = 0; j < 4; ++j) v[j] *= dropout_scale(e.drop_seed, q + j, e.drop_thresh, e.drop_inv_keep);
         }
     }
-    if (a.residual && !a.res_pre_act) {
+    if (fl & EPI_RES_POST) {
         float r[4];
-        const long long ridx = dbase + mr * a.ldr + n;   // residual shares D's batch strides
-        if (a.out_f32) load4<float>(a.residual, ridx, vec, nvalid, r);
-        else load4<T>(a.residual, ridx, vec, nvalid, r);
+        const long long ridx = dbase + mr * e.ldr + n;   // residual shares D's batch strides
+        if (out_f32) load4<float>(e.residual, ridx, vec, nvalid, r);
+        else load4<T>(e.residual, ridx, vec, nvalid, r);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += r[j];
     }
-    if (a.out_f32) {
-        if (a.accumulate) {
+    if (out_f32) {
+        if (fl & EPI_ACCUM) {
             float o[4];
             load4<float>(Dp, didx, vec, nvalid, o);
 #pragma unroll
@@ -470,6 +554,7 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
     const int wm = wave >> 1, wn = wave & 1;
     const int g = lane >> 4, l15 = lane & 15;
     int tm, tn;
+    HS_STAMP(0);
     tile_from_block(a, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.z;
@@ -674,12 +759,14 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
 
     if (ntiles > 0) {
         stage_dma(0, k_of(0));
+        HS_STAMP(1);
         if (ntiles > 1) stage_dma(1, k_of(1));
         if (ntiles > 2) stage_dma(2, k_of(2));
         if (ntiles > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
         else if (ntiles > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        HS_STAMP(2);
         bf16x8 a0[FM], b0[FN], a1[FM], b1[FN];
         load_frags(0, 0, a0, b0);
         static_assert(KS == 1 || KS == 2, "BK must be 32 or 64");
@@ -708,6 +795,7 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
         }
     }
 
+    HS_STAMP(3);
     // ---- optional: column statistics of this tile for a following BatchNorm --------------------------
     // Rows of the tile beyond M hold exact zeros (their operand rows were zero-filled), so plain sums over the whole
     // tile with the true row count give the tile's (count, mean, M2).  Per column: in-lane sum over the FM row
@@ -762,6 +850,10 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
     }
 
     // ---- epilogue: lane owns m = .. + l15, n = .. + 4g + {0..3} ---------------------------------
+    const Epi epi = make_epi(a);
+    int split_k = a.split_k, argM = a.M, argN = a.N;
+    float* splitk_ws = a.splitk_ws;
+    pin_sgpr(split_k); pin_sgpr(argM); pin_sgpr(argN); pin_sgpr(splitk_ws);
     if constexpr (A_RC) {
         if (do_rowsum && g == 0) {           // every n of the ones-operand holds the same sum: lanes 0..15 write one row each
 #pragma unroll
@@ -774,25 +866,67 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
             }
         }
     }
+    if (split_k > 1) {
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm * WM + i * 16 + l15;
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * WM + i * 16 + l15;
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * WN + j * 16 + 4 * g;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (a.split_k > 1) {
-                if (m < a.M && n < a.N) {
-                    float* w = a.splitk_ws + ((long long)z * a.M + m) * a.N + n;
-                    if (n + 3 < a.N && (a.N & 3) == 0) *(f32x4*)w = f32x4{v[0], v[1], v[2], v[3]};
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + 4 * g;
+                if (m < argM && n < argN) {
+                    HS_GLOBAL float* w = (HS_GLOBAL float*)splitk_ws + ((long long)z * argM + m) * argN + n;
+                    if (n + 3 < argN && (argN & 3) == 0)
+                        *(HS_GLOBAL f32x4*)w = f32x4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                     else
-                        for (int e = 0; e < 4 && n + e < a.N; ++e) w[e] = v[e];
+                        for (int e = 0; e < 4 && n + e < argN; ++e) w[e] = acc[i][j][e];
                 }
-            } else {
-                epilogue4<T>(a, d_boff, z, m, n, v);
             }
         }
+        HS_STAMP(4);
+        return;
     }
+    auto run = [&](auto cf, auto full) {
+        constexpr int CF = decltype(cf)::value;
+        constexpr bool FULL = decltype(full)::value;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * WM + i * 16 + l15;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + 4 * g;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                epilogue4<T, CF, FULL>(a, epi, d_boff, z, m, n, v);
+                if (i == 0 && j == 0) HS_STAMP(5);
+            }
+        }
+    };
+    // whole tile inside the matrix and 4-wide storable: one of the feature sets the training / inference steps use gets
+    // branch-free code; anything else (edge tiles, rare combinations) takes the generic body
+    const bool full = (epi.flags & EPI_VEC) && m0 + BM <= argM && n0 + BN <= argN;
+    bool done = false;
+    if (full) {
+        done = true;
+#define HS_EPI_CASE(F) case (F): run(std::integral_constant<int, (F)>{}, std::true_type{}); break
+        switch (epi.flags) {
+            HS_EPI_CASE(EPI_VEC);                                                     // plain bf16 result
+            HS_EPI_CASE(EPI_VEC | EPI_BIAS);                                          // Linear
+            HS_EPI_CASE(EPI_VEC | EPI_BIAS | EPI_GELU | EPI_PREACT);                  // FFN up-projection
+            HS_EPI_CASE(EPI_VEC | EPI_BIAS | EPI_RES_POST);                           // dense + residual (eval / p = 0)
+            HS_EPI_CASE(EPI_VEC | EPI_BIAS | EPI_DROP | EPI_RES_POST);                // dense + hidden dropout + residual
+            HS_EPI_CASE(EPI_VEC | EPI_MUL_GELU);                                      // data gradient through GELU
+            HS_EPI_CASE(EPI_VEC | EPI_RES_POST);                                      // data gradient + skip gradient
+            HS_EPI_CASE(EPI_VEC | EPI_OUT_F32);                                       // weight gradient (f32)
+            HS_EPI_CASE(EPI_VEC | EPI_OUT_F32 | EPI_SEG);                             // fused Q/K/V weight gradient
+            HS_EPI_CASE(EPI_VEC | EPI_PARITY);                                        // stride-2 conv data gradient
+            HS_EPI_CASE(EPI_VEC | EPI_BIAS | EPI_COLSCALE | EPI_RELU);                // folded conv+BN+ReLU (inference)
+            HS_EPI_CASE(EPI_VEC | EPI_BIAS | EPI_COLSCALE);                           // folded conv+BN
+            HS_EPI_CASE(EPI_VEC | EPI_BIAS | EPI_COLSCALE | EPI_RELU | EPI_RES_PRE);  // folded conv+BN+add+ReLU
+            default: done = false;
+        }
+#undef HS_EPI_CASE
+    }
+    if (!done) run(std::integral_constant<int, -1>{}, std::false_type{});
+    HS_STAMP(4);
 }
 
 // ================================================================================================
@@ -953,6 +1087,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs a) {
     }
 
     // lane owns m = .. + l31; register e -> n = 8*(e>>2) + 4*hh + (e&3)
+    const Epi epi = make_epi(a);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * WM + i * 32 + l31;
@@ -970,7 +1105,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs a) {
                             for (int e = 0; e < 4 && n + e < a.N; ++e) w[e] = v[e];
                     }
                 } else {
-                    epilogue4<T>(a, d_boff, z, m, n, v);
+                    epilogue4<T>(a, epi, d_boff, z, m, n, v);
                 }
             }
         }
@@ -982,6 +1117,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
     const long long nq = ((long long)a.N + 3) / 4;
     const long long total = (long long)a.M * nq;
+    const Epi epi = make_epi(a);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int m = (int)(i / nq), n = (int)(i - (long long)m * nq) * 4;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -995,7 +1131,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
                 for (int e = 0; e < nvalid; ++e) v[e] += w[e];
             }
         }
-        epilogue4<T>(a, 0, 0, m, n, v);
+        epilogue4<T>(a, epi, 0, 0, m, n, v);
     }
 }
 
