@@ -151,6 +151,7 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     a.colscale = p->colscale;
     a.res_pre_act = p->residual_before_act;
     a.stamps = g_dbg_stamps;
+    a.epi_generic = (g_dbg_ablate & 32) ? 1 : 0;
     a.rowsum[0] = p->rowsum_a;
     a.rowsum[1] = p->rowsum_seg[0];
     a.rowsum[2] = p->rowsum_seg[1];
@@ -243,6 +244,10 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
         if (p->residual) vs = vs && (p->ldr % 4 == 0) && ((((uintptr_t)p->residual) % (4 * oesz)) == 0);
         if (p->mul_src) vs = vs && (p->ldm % 4 == 0) && ((((uintptr_t)p->mul_src) % (4 * esz)) == 0);
         a.vec_store = vs;
+        bool v16 = bf16 && !a.out_f32 && (p->N % 8 == 0) && (p->ldd % 8 == 0) && ((((uintptr_t)p->D) & 15) == 0);
+        if (batch > 1) v16 = v16 && (p->d_bs0 % 8 == 0) && (p->d_bs1 % 8 == 0);
+        if (p->D_preact) v16 = v16 && ((((uintptr_t)p->D_preact) & 15) == 0);
+        a.vec16 = v16 ? 1 : 0;
     }
 
     // tile selection.  Measured on MI355X (tools/gemm_bench.py, profiles/): the GEMMs of this workload are

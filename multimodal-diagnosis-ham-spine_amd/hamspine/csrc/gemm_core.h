@@ -66,6 +66,8 @@ struct GemmArgs {
     int seg_rows;              // >0: output rows are split over D / D_seg[0] / D_seg[1]
     char* D_seg[2];
     float* rowsum[3];          // optional (row-contiguous A): rowsum[seg][m] = sum_k A[k][m], the bias gradient of a wgrad GEMM
+    int vec16;                    // bf16 result rows allow 16-byte (8-column) stores: N, ldd, batch strides % 8 == 0, bases 16-byte aligned
+    int epi_generic;              // measurement only (hs_gemm_debug bit 32): always take the generic epilogue body
     unsigned long long* stamps;   // measurement only (hs_gemm_debug_stamps): 6 shader-clock stamps per workgroup, else NULL
 };
 // stamp k of this workgroup: 0 start, 1 first DMA issued, 2 first tile landed (barrier passed), 3 K loop done,
@@ -99,8 +101,8 @@ __device__ __forceinline__ long long parity_row(const GemmArgs& a, int m) {   //
 // ------------------------------------------------------------------------------------------------
 // epilogue for 4 consecutive n of one row m.  TIn = element type of mul_src; TOut chosen at run time.
 // ------------------------------------------------------------------------------------------------
-// Epilogue operands are device-global memory; the pointers come out of pin_sgpr() as opaque values, so the address space
-// is stated explicitly (otherwise every access becomes a flat_ instruction).
+// Epilogue operands are device-global memory: the address space is stated explicitly so that no access can degrade to a
+// flat_ instruction.
 #define HS_GLOBAL __attribute__((address_space(1)))
 template <typename T>
 __device__ __forceinline__ void load4(const char* base, long long idx, bool vec, int nvalid, float* f) {
@@ -139,38 +141,19 @@ __device__ __forceinline__ void store4(char* base, long long idx, bool vec, int 
     }
 }
 
-// Everything the epilogue reads from the kernel arguments, fetched ONCE per workgroup.  The arguments live in the kernarg
-// segment; read where they are used, each of the ~12 feature tests of every output fragment became an `s_load` +
-// `s_waitcnt lgkmcnt(0)` (the register allocator prefers re-loading to keeping: 44 scalar loads after the last MFMA),
-// which made the epilogue of a 128x64 tile 5.7 us of an 13 us workgroup lifetime (tools/gemm_stamps.py).  Here the
-// features are folded into one bit mask and the values are pinned into registers (the empty asm makes them opaque,
-// so they cannot be rematerialised from memory).
+// Epilogue features of a launch as one bit mask.  The generic epilogue body tests ~12 of them per output fragment (each an
+// `s_load` + wait on a kernel argument and a branch; ~650 instructions of code per fragment): tools/gemm_stamps.py measured
+// it at 6 us of the 12.4 us a 128x64 workgroup lives.  The hot feature sets therefore get compile-time-specialised bodies.
 enum {
     EPI_BIAS = 1, EPI_COLSCALE = 2, EPI_MUL_GELU = 4, EPI_MUL_RELU = 8, EPI_SEG = 16, EPI_PREACT = 32, EPI_RES_PRE = 64,
     EPI_RES_POST = 128, EPI_RELU = 256, EPI_GELU = 512, EPI_DROP = 1024, EPI_OUT_F32 = 2048, EPI_ACCUM = 4096, EPI_VEC = 8192,
-    EPI_PARITY = 16384
+    EPI_PARITY = 16384, EPI_VEC16 = 32768
 };
-struct Epi {
-    unsigned flags;
-    int M, N, ldd, ldr, ldm, seg_rows;
-    float alpha, drop_inv_keep;
-    unsigned drop_thresh;
-    unsigned long long drop_seed;
-    const float* bias;
-    const float* colscale;
-    const char* mul_src;
-    const char* residual;
-    char* D;
-    char* D_seg0;
-    char* D_seg1;
-    char* D_preact;
-};
-template <typename V>
-__device__ __forceinline__ void pin_sgpr(V& v) {
-    asm volatile("" : "+s"(v));
-}
-__device__ __forceinline__ Epi make_epi(const GemmArgs& a) {
-    Epi e;
+// The feature mask of a launch, computed once per workgroup.  (A struct holding copies of all epilogue arguments was tried
+// first: it ended up on the stack -- 120 B of scratch per lane, measured as 2.75x the algorithmic HBM write bytes of a GEMM
+// -- so the epilogue reads the kernel arguments directly; with a compile-time feature set that is a handful of scalar loads
+// in straight-line code.)
+__device__ __forceinline__ unsigned epi_flags(const GemmArgs& a) {
     unsigned f = 0;
     if (a.bias) f |= EPI_BIAS;
     if (a.colscale) f |= EPI_COLSCALE;
@@ -186,52 +169,42 @@ __device__ __forceinline__ Epi make_epi(const GemmArgs& a) {
     if (a.accumulate) f |= EPI_ACCUM;
     if (a.vec_store) f |= EPI_VEC;
     if (a.parity) f |= EPI_PARITY;
-    e.flags = f;
-    e.M = a.M; e.N = a.N; e.ldd = a.ldd; e.ldr = a.ldr; e.ldm = a.ldm; e.seg_rows = a.seg_rows;
-    e.alpha = a.alpha; e.drop_inv_keep = a.drop_inv_keep;
-    e.drop_thresh = a.drop_thresh; e.drop_seed = a.drop_seed;
-    e.bias = a.bias; e.colscale = a.colscale; e.mul_src = a.mul_src; e.residual = a.residual;
-    e.D = a.D; e.D_seg0 = a.D_seg[0]; e.D_seg1 = a.D_seg[1]; e.D_preact = a.D_preact;
-    pin_sgpr(e.flags);
-    pin_sgpr(e.M); pin_sgpr(e.N); pin_sgpr(e.ldd); pin_sgpr(e.ldr); pin_sgpr(e.ldm); pin_sgpr(e.seg_rows);
-    unsigned al = __float_as_uint(e.alpha), ik = __float_as_uint(e.drop_inv_keep);
-    pin_sgpr(al); pin_sgpr(ik);
-    e.alpha = __uint_as_float(al); e.drop_inv_keep = __uint_as_float(ik);
-    pin_sgpr(e.drop_thresh); pin_sgpr(e.drop_seed);
-    pin_sgpr(e.bias); pin_sgpr(e.colscale); pin_sgpr(e.mul_src); pin_sgpr(e.residual);
-    pin_sgpr(e.D); pin_sgpr(e.D_seg0); pin_sgpr(e.D_seg1); pin_sgpr(e.D_preact);
-    return e;
+    if (a.vec16) f |= EPI_VEC16;
+    return f;
 }
 
 // CF >= 0: the feature set is a compile-time constant (straight-line code for the combinations the training step uses, see
 // the dispatch in the kernel); CF < 0: tested at run time.  FULL: the tile lies inside the matrix and rows are 4-wide
 // storable, so no lane needs bounds or tail handling.  The fully generic body is ~650 instructions of branches per fragment
 // (x8-16 fragments: > 40 KB of code walked sparsely), which is what made the epilogue as long as the K loop.
-template <typename T, int CF = -1, bool FULL = false>
-__device__ __forceinline__ void epilogue4(const GemmArgs& a, const Epi& e, long long dbase, int z, int m, int n, float* v) {
+// DEFER: nothing is stored; v returns the final values and pv the pre-activation copy (EPI_PREACT), for the caller's
+// 16-byte paired stores.
+template <typename T, int CF = -1, bool FULL = false, bool DEFER = false>
+__device__ __forceinline__ void epilogue4(const GemmArgs& a, unsigned rt_flags, long long dbase, int z, int m, int n,
+                                          float* v, float* pv = nullptr) {
     if constexpr (!FULL) {
-        if (m >= e.M || n >= e.N) return;
+        if (m >= a.M || n >= a.N) return;
     }
-    const unsigned fl = CF >= 0 ? (unsigned)CF : e.flags;
+    const unsigned fl = CF >= 0 ? (unsigned)CF : rt_flags;
     const long long mr = (fl & EPI_PARITY) ? parity_row(a, m) : (long long)m;   // row of D / residual / multiplier source
-    const int nvalid = FULL ? 4 : min(4, e.N - n);
+    const int nvalid = FULL ? 4 : min(4, a.N - n);
     const bool vec = FULL ? true : ((fl & EPI_VEC) && nvalid == 4);
     const bool out_f32 = fl & EPI_OUT_F32;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] *= e.alpha;
+    for (int j = 0; j < 4; ++j) v[j] *= a.alpha;
     if (fl & EPI_COLSCALE) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (j < nvalid) v[j] *= ((const HS_GLOBAL float*)e.colscale)[n + j];
+            if (j < nvalid) v[j] *= ((const HS_GLOBAL float*)a.colscale)[n + j];
     }
     if (fl & EPI_BIAS) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (j < nvalid) v[j] += ((const HS_GLOBAL float*)e.bias)[n + j];
+            if (j < nvalid) v[j] += ((const HS_GLOBAL float*)a.bias)[n + j];
     }
     if (fl & (EPI_MUL_GELU | EPI_MUL_RELU)) {
         float u[4];
-        load4<T>(e.mul_src, mr * e.ldm + n, vec, nvalid, u);   // mul_src is never batched
+        load4<T>(a.mul_src, mr * a.ldm + n, vec, nvalid, u);   // mul_src is never batched
         if (fl & EPI_MUL_GELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] *= gelu_grad_t<T>(u[j]);
@@ -240,22 +213,27 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, const Epi& e, long 
             for (int j = 0; j < 4; ++j) v[j] = u[j] > 0.f ? v[j] : 0.f;
         }
     }
-    char* Dp = e.D;
-    long long didx = dbase + mr * e.ldd + n;
+    char* Dp = a.D;
+    long long didx = dbase + mr * a.ldd + n;
     if (fl & EPI_SEG) {
-        const int seg = m / e.seg_rows;
-        if (seg > 0) Dp = seg == 1 ? e.D_seg0 : e.D_seg1;
-        didx = (long long)(m - seg * e.seg_rows) * e.ldd + n;
+        const int seg = m / a.seg_rows;
+        if (seg > 0) Dp = seg == 1 ? a.D_seg[0] : a.D_seg[1];
+        didx = (long long)(m - seg * a.seg_rows) * a.ldd + n;
     }
     if (fl & EPI_PREACT) {
-        if (out_f32) store4<float>(e.D_preact, didx, vec, nvalid, v);
-        else store4<T>(e.D_preact, didx, vec, nvalid, v);
+        if constexpr (DEFER) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pv[j] = v[j];
+        } else {
+            if (out_f32) store4<float>(a.D_preact, didx, vec, nvalid, v);
+            else store4<T>(a.D_preact, didx, vec, nvalid, v);
+        }
     }
     if (fl & EPI_RES_PRE) {
         float r[4];
-        const long long ridx = dbase + mr * e.ldr + n;
-        if (out_f32) load4<float>(e.residual, ridx, vec, nvalid, r);
-        else load4<T>(e.residual, ridx, vec, nvalid, r);
+        const long long ridx = dbase + mr * a.ldr + n;
+        if (out_f32) load4<float>(a.residual, ridx, vec, nvalid, r);
+        else load4<T>(a.residual, ridx, vec, nvalid, r);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += r[j];
     }
@@ -267,25 +245,26 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, const Epi& e, long 
         for (int j = 0; j < 4; ++j) v[j] = gelu_fwd_t<T>(v[j]);
     }
     if (fl & EPI_DROP) {
-        const unsigned long long q = ((unsigned long long)z * e.M + m) * (unsigned long long)e.N + n;
+        const unsigned long long q = ((unsigned long long)z * a.M + m) * (unsigned long long)a.N + n;
         if ((q & 3) == 0) {
             float sc[4];
-            dropout_scale4(e.drop_seed, q, e.drop_thresh, e.drop_inv_keep, sc);
+            dropout_scale4(a.drop_seed, q, a.drop_thresh, a.drop_inv_keep, sc);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] *= sc[j];
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= dropout_scale(e.drop_seed, q + j, e.drop_thresh, e.drop_inv_keep);
+            for (int j = 0; j < 4; ++j) v[j] *= dropout_scale(a.drop_seed, q + j, a.drop_thresh, a.drop_inv_keep);
         }
     }
     if (fl & EPI_RES_POST) {
         float r[4];
-        const long long ridx = dbase + mr * e.ldr + n;   // residual shares D's batch strides
-        if (out_f32) load4<float>(e.residual, ridx, vec, nvalid, r);
-        else load4<T>(e.residual, ridx, vec, nvalid, r);
+        const long long ridx = dbase + mr * a.ldr + n;   // residual shares D's batch strides
+        if (out_f32) load4<float>(a.residual, ridx, vec, nvalid, r);
+        else load4<T>(a.residual, ridx, vec, nvalid, r);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += r[j];
     }
+    if constexpr (DEFER) return;
     if (out_f32) {
         if (fl & EPI_ACCUM) {
             float o[4];
@@ -534,6 +513,59 @@ __device__ __forceinline__ int rc_logical_chunk(int k, int pcc) {
 // logical chunk belongs at this LDS slot) and again on the fragment reads.  Out-of-range source offsets
 // write zeros (verified on gfx950), which is how M/N/K tails and conv padding are predicated.
 // Contract for K-contiguous operands: K % 8 == 0, or the row is zero padded up to the next multiple of 8.
+// The epilogue of one workgroup tile for a compile-time feature set CF (or the run-time mask `epi` when CF < 0).
+template <typename T, int CF, bool FULL, int FM, int FN, int WM, int WN>
+__device__ __forceinline__ void run_epilogue(const GemmArgs& a, const unsigned epi, f32x4 (&acc)[FM][FN], int m0, int n0, int wm,
+                                             int wn, int l15, int g, long long d_boff, int z) {
+        // bf16 results of full tiles: 8-byte stores of the lane-owned 4 columns reach memory as separate partial-sector
+        // writes once the epilogue is fast (measured 2.75x the algorithmic write bytes), so two column fragments are
+        // exchanged between lane pairs (g, g^1) and every lane stores 8 consecutive columns = 16 bytes: each row gets whole
+        // 64-byte sectors from one instruction.
+        if constexpr (FULL && CF >= 0 && !(CF & (EPI_OUT_F32 | EPI_SEG | EPI_PARITY)) && (FN % 2 == 0) && sizeof(T) == 2) {
+            const bool odd = g & 1;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * WM + i * 16 + l15;
+#pragma unroll
+                for (int j = 0; j < FN; j += 2) {
+                    const int n = n0 + wn * WN + j * 16 + 4 * g;
+                    float v0[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    float v1[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+                    float p0[4], p1[4];
+                    epilogue4<T, CF, true, true>(a, epi, d_boff, z, m, n, v0, p0);
+                    epilogue4<T, CF, true, true>(a, epi, d_boff, z, m, n + 16, v1, p1);
+                    const long long didx = d_boff + (long long)m * a.ldd + (odd ? n + 12 : n);
+                    auto pair_store = [&](char* base, const float* x0, const float* x1) {
+                        const bf16x4 b0 = {(bf16_t)x0[0], (bf16_t)x0[1], (bf16_t)x0[2], (bf16_t)x0[3]};
+                        const bf16x4 b1 = {(bf16_t)x1[0], (bf16_t)x1[1], (bf16_t)x1[2], (bf16_t)x1[3]};
+                        const u32x2 a0 = __builtin_bit_cast(u32x2, b0), a1 = __builtin_bit_cast(u32x2, b1);
+                        const u32x2 send = odd ? a0 : a1;       // even lanes keep fragment j, odd lanes fragment j + 1
+                        u32x2 recv;
+                        recv[0] = __shfl_xor(send[0], 16, 64);
+                        recv[1] = __shfl_xor(send[1], 16, 64);
+                        const u32x4 o = odd ? u32x4{recv[0], recv[1], a1[0], a1[1]} : u32x4{a0[0], a0[1], recv[0], recv[1]};
+                        *(HS_GLOBAL u32x4*)((HS_GLOBAL bf16_t*)base + didx) = o;
+                    };
+                    if constexpr (CF & EPI_PREACT) pair_store(a.D_preact, p0, p1);
+                    pair_store(a.D, v0, v1);
+                    if (i == 0 && j == 0) HS_STAMP(5);
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * WM + i * 16 + l15;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + 4 * g;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                epilogue4<T, CF, FULL>(a, epi, d_boff, z, m, n, v);
+                if (i == 0 && j == 0) HS_STAMP(5);
+            }
+        }
+}
+
 // WGM: waves along M (x 2 along N): 2 -> 256 threads (the default), 4 -> 512 threads for the 256-row tile.
 template <int BM, int BN, int BK, int AK, int BKIND, bool VEC, int WGM = 2>
 __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) {
@@ -850,10 +882,9 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
     }
 
     // ---- epilogue: lane owns m = .. + l15, n = .. + 4g + {0..3} ---------------------------------
-    const Epi epi = make_epi(a);
-    int split_k = a.split_k, argM = a.M, argN = a.N;
+    const unsigned epi = epi_flags(a);
+    const int split_k = a.split_k, argM = a.M, argN = a.N;
     float* splitk_ws = a.splitk_ws;
-    pin_sgpr(split_k); pin_sgpr(argM); pin_sgpr(argN); pin_sgpr(splitk_ws);
     if constexpr (A_RC) {
         if (do_rowsum && g == 0) {           // every n of the ones-operand holds the same sum: lanes 0..15 write one row each
 #pragma unroll
@@ -885,29 +916,17 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
         HS_STAMP(4);
         return;
     }
-    auto run = [&](auto cf, auto full) {
-        constexpr int CF = decltype(cf)::value;
-        constexpr bool FULL = decltype(full)::value;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int m = m0 + wm * WM + i * 16 + l15;
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int n = n0 + wn * WN + j * 16 + 4 * g;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                epilogue4<T, CF, FULL>(a, epi, d_boff, z, m, n, v);
-                if (i == 0 && j == 0) HS_STAMP(5);
-            }
-        }
-    };
     // whole tile inside the matrix and 4-wide storable: one of the feature sets the training / inference steps use gets
     // branch-free code; anything else (edge tiles, rare combinations) takes the generic body
-    const bool full = (epi.flags & EPI_VEC) && m0 + BM <= argM && n0 + BN <= argN;
+    const bool full = !a.epi_generic && (epi & EPI_VEC) && m0 + BM <= argM && n0 + BN <= argN;
     bool done = false;
     if (full) {
         done = true;
-#define HS_EPI_CASE(F) case (F): run(std::integral_constant<int, (F)>{}, std::true_type{}); break
-        switch (epi.flags) {
+#define HS_EPI_CASE(F) case (F): run_epilogue<T, (F), true, FM, FN, WM, WN>(a, epi, acc, m0, n0, wm, wn, l15, g, d_boff, z); break
+        const bool v16 = epi & EPI_VEC16;
+        const unsigned key = epi & ~EPI_VEC16;
+        if (!v16 && !(key & EPI_OUT_F32)) done = false;      // bf16 rows that cannot take 16-byte stores: generic body
+        else switch (key) {
             HS_EPI_CASE(EPI_VEC);                                                     // plain bf16 result
             HS_EPI_CASE(EPI_VEC | EPI_BIAS);                                          // Linear
             HS_EPI_CASE(EPI_VEC | EPI_BIAS | EPI_GELU | EPI_PREACT);                  // FFN up-projection
@@ -925,7 +944,7 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
         }
 #undef HS_EPI_CASE
     }
-    if (!done) run(std::integral_constant<int, -1>{}, std::false_type{});
+    if (!done) run_epilogue<T, -1, false, FM, FN, WM, WN>(a, epi, acc, m0, n0, wm, wn, l15, g, d_boff, z);
     HS_STAMP(4);
 }
 
@@ -1087,7 +1106,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs a) {
     }
 
     // lane owns m = .. + l31; register e -> n = 8*(e>>2) + 4*hh + (e&3)
-    const Epi epi = make_epi(a);
+    const unsigned epi = epi_flags(a);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * WM + i * 32 + l31;
@@ -1117,7 +1136,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
     const long long nq = ((long long)a.N + 3) / 4;
     const long long total = (long long)a.M * nq;
-    const Epi epi = make_epi(a);
+    const unsigned epi = epi_flags(a);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int m = (int)(i / nq), n = (int)(i - (long long)m * nq) * 4;
         float v[4] = {0.f, 0.f, 0.f, 0.f};

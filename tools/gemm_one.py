@@ -11,7 +11,7 @@ import gemm_bench as gb  # noqa: E402
 
 kind, M, N, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 cfg = int(sys.argv[5]) if len(sys.argv) > 5 else -1
-gb.lib.hs_gemm_debug(cfg, 0)
+gb.lib.hs_gemm_debug(cfg, int(sys.argv[6]) if len(sys.argv) > 6 else 0)
 fn = gb.gemm_case(kind, M, N, K)
 for _ in range(5):
     fn()
