@@ -134,7 +134,9 @@ int32_t hs_gemm_suggest_split(int32_t M, int32_t N, int32_t K, int32_t dtype);
    Classes: 0 bf16 GEMM, 1 bf16 implicit-GEMM conv, 2 f32 GEMM, 3 f32 conv.  hs_prof_collect synchronises the
    device, fills 4 entries of algorithmic flops / elapsed ms / launch counts and clears the records. */
 /* measurement only: force a tile configuration (0 128x128, 1 128x64, 2 64x64, -1 auto) and ablation bits
-   (16 = plain n-fastest tile order instead of the L2-grouped one; results stay correct). */
+   (16 = plain n-fastest tile order instead of the L2-grouped one; 32 = always the generic epilogue body instead of
+   the specialised ones; results stay correct).  cfg also accepts 4 (256x128, 8 waves), 5 (128x128, BK 32), 6 (256x128, BK 32)
+   for plain bf16 GEMMs. */
 void hs_gemm_debug(int32_t cfg_override, int32_t ablate);
 /* measurement only: while device_buffer is not NULL every bf16 hs_gemm launch writes 6 shader-clock stamps per workgroup
    (start, first DMA issued, first K tile landed, K loop done, epilogue done, unused) to it; size it 48 bytes x workgroups. */
