@@ -70,7 +70,7 @@ struct GemmArgs {
     int epi_generic;              // measurement only (hs_gemm_debug bit 32): always take the generic epilogue body
     unsigned long long* stamps;   // measurement only (hs_gemm_debug_stamps): 6 shader-clock stamps per workgroup, else NULL
 };
-// stamp k of this workgroup: 0 start, 1 first DMA issued, 2 first tile landed (barrier passed), 3 K loop done,
+// stamp k of this workgroup: 0 start (clock taken at entry, stored together with stamp 1), 1 first DMA issued, 2 first tile landed (barrier passed), 3 K loop done,
 // 4 epilogue done (stores issued); slot 5 = XCC/CU id bits of HW_ID
 #define HS_STAMP(k)                                                                                              \
     do {                                                                                                         \
@@ -586,7 +586,17 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
     const int wm = wave >> 1, wn = wave & 1;
     const int g = lane >> 4, l15 = lane & 15;
     int tm, tn;
-    HS_STAMP(0);
+    const unsigned long long t_entry = __builtin_readcyclecounter();   // stamp 0, written with stamp 1 (no argument load here)
+    {   // one batch of scalar loads for everything the set-up reads: left to the scheduler they were 5-7 dependent
+        // s_load + s_waitcnt round trips in front of the first DMA (tools/gemm_stamps.py: 1.3-1.45 us of set-up)
+        const int q0 = a.tiles_m, q1 = a.tiles_n, q2 = a.group_m, q3 = a.split_k, q4 = a.k_per_split, q5 = a.batch_inner;
+        const int q6 = a.M, q7 = a.N, q8 = a.K, q9 = a.lda, q10 = a.ldb;
+        const char* pa = a.A;
+        const char* pb = a.B;
+        const unsigned long long ba = a.a_bytes, bb = a.b_bytes;
+        asm volatile("" ::"s"(q0), "s"(q1), "s"(q2), "s"(q3), "s"(q4), "s"(q5), "s"(q6), "s"(q7), "s"(q8), "s"(q9), "s"(q10),
+                     "s"(pa), "s"(pb), "s"(ba), "s"(bb));
+    }
     tile_from_block(a, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.z;
@@ -792,6 +802,7 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
     if (ntiles > 0) {
         stage_dma(0, k_of(0));
         HS_STAMP(1);
+        if (a.stamps && threadIdx.x == 0) a.stamps[((long long)blockIdx.z * gridDim.x + blockIdx.x) * 6] = t_entry;
         if (ntiles > 1) stage_dma(1, k_of(1));
         if (ntiles > 2) stage_dma(2, k_of(2));
         if (ntiles > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
