@@ -130,8 +130,10 @@ def gpu_leg(args, rank, world, local_rank):
     lib.hs_prof_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     fl, ms, cnt = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_int64 * 4)()
     # one kernel at a time for this leg (no weight-gradient side stream, towers back to back): the events then bracket
-    # the kernel alone, which is what a per-kernel roofline means; the timed region above ran with both overlaps on
+    # the kernel alone, which is what a per-kernel roofline means; the timed region above ran with the default streams
+    # (text tower on its own stream; weight-gradient side stream only if HAMSPINE_OVERLAP=1)
     lib.hs_set_overlap(0)
+    tower_default = os.environ.get("HAMSPINE_TOWER_OVERLAP", "1")
     os.environ["HAMSPINE_TOWER_OVERLAP"] = "0"
     step()
     fence()
@@ -178,8 +180,8 @@ def gpu_leg(args, rank, world, local_rank):
         step()
         L.check(lib.hs_prof_dump(args.gemm_log.encode()), "hs_prof_dump")
         lib.hs_prof_enable(0)
-    lib.hs_set_overlap(1)
-    os.environ["HAMSPINE_TOWER_OVERLAP"] = "1"
+    lib.hs_set_overlap(1 if os.environ.get("HAMSPINE_OVERLAP") == "1" else 0)
+    os.environ["HAMSPINE_TOWER_OVERLAP"] = tower_default
     return dt, final_loss, roofline, nparams
 
 

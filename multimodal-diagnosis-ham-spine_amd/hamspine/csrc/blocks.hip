@@ -63,11 +63,15 @@ static hipStream_t g_side_stream[16] = {};
 static hipEvent_t g_events[16][64] = {};
 static int g_event_next[16] = {};
 static std::mutex g_side_mu;
+// Weight-gradient GEMMs of a composite on a side stream beside its data-gradient chain.  OFF by default since the GEMM
+// epilogue work: with workgroups that live 7.8 instead of 12.4 us a single GEMM fills the chip well enough that running two
+// at once only makes them contend (C2 step 14.5 ms with the side stream, 12.6 ms without; it was 21.5 -> 19.7 ms the other
+// way round when it was introduced).  HAMSPINE_OVERLAP=1 / hs_set_overlap(1) switch it on.
 static int g_overlap = -1;   // -1: take HAMSPINE_OVERLAP from the environment on first use
 static bool overlap_enabled() {
     if (g_overlap < 0) {
         const char* e = getenv("HAMSPINE_OVERLAP");
-        g_overlap = (e && e[0] == '0') ? 0 : 1;
+        g_overlap = (e && e[0] == '1') ? 1 : 0;
     }
     return g_overlap == 1;
 }

@@ -19,7 +19,7 @@ python3 tools/profile_summary.py $OUT/iso/iso_results.db 16 profiles/${TAG}_fina
   "MI355X, workload C2 (ResNet50 + BERT-base L=128 + FusionModule + MLP head, B=32, bf16). Both stream overlaps off: every kernel runs alone, so durations are per-kernel costs (the configuration bench.py's roofline leg uses). 16 steps in the trace (3 warm-up + 10 timed + 3 of the roofline leg). bench.py's live figure for the same family (HIP events around each launch) reads ~6 us more per launch: the event bracket's own dispatch latency, which bench.py measures around an empty kernel and reports as event_bracket_us. The BERT attention core runs in attn_fwd_fused_kernel / attn_bwd_fused_kernel, so its FLOP are not in the GEMM family's count (strided data gradients are counted with the filter taps they execute)." > /dev/null
 python3 tools/profile_summary.py $OUT/ovl/ovl_results.db 16 profiles/${TAG}_final_overlapped \
   "rocprofv3 --kernel-trace of \`python bench.py --steps 10 --warmup 3 --no-cpu-baseline\` (${TAG}, final, default configuration)" \
-  "Default configuration: weight-gradient GEMMs on a side stream, text tower on its own stream. Kernels share the GPU, so individual durations are inflated and their sum exceeds the wall clock. 16 steps in the trace (13 overlapped + 3 un-overlapped steps of the roofline leg)." > /dev/null
+  "Default configuration: text tower on its own stream beside the image tower (the weight-gradient side stream is off by default). Kernels of the two towers share the GPU, so individual durations are inflated and their sum exceeds the wall clock. 16 steps in the trace (13 overlapped + 3 un-overlapped steps of the roofline leg)." > /dev/null
 python3 tools/pmc_traffic.py $OUT/fetch/fetch_results.db $OUT/write/write_results.db profiles/${TAG}_pmc_traffic.json > /dev/null
 head -8 profiles/${TAG}_final_isolated_summary.md
 cat profiles/${TAG}_pmc_traffic.json | head -12
