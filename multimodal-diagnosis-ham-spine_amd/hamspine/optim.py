@@ -25,6 +25,13 @@ class _FusedAdamBase(torch.optim.Optimizer):
         (scripts/train.py:373-385, mibf_net/train_resnet.py:29-33)."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._overlap = bool(overlap_backward)
+        if self._overlap:
+            # KNOWN ISSUE (end of round 1): this optional mode is validated with the composites' weight-gradient side stream
+            # on.  With the side stream off (the default since the GEMM epilogue work) the update of the last gradients of
+            # backward (the stem) can come out wrong (tests/test_product_gpu.py::test_optimizer_in_backward..., cause not yet
+            # found).  The mode measured neutral-to-worse in both configurations and nothing uses it by default, so it
+            # switches the side stream back on for the process.
+            L.lib().hs_set_overlap(1)
         self._chunk = int(overlap_chunk)
         self._pending, self._pending_n = [], 0
         self._stream = None
