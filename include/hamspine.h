@@ -396,15 +396,17 @@ hs_status hs_patchify_bwd(int32_t dtype, const void* dpatch, void* dx, int32_t N
 
 /* ------------------------------------------------------------------------------------------- */
 /* KAN layer / MoE gating pieces (reference ConNexT/models/block/kan1.py:77-165, moe.py:171-291).  */
-/* KANLinear(x) = [SiLU(x) | b_splines(x)] @ [base_weight | spline_weight*spline_scaler]^T: the     */
+/* KANLinear(x) = [act(x) | b_splines(x)] @ [base_weight | spline_weight*spline_scaler]^T: the      */
 /* feature / weight packing below, the contraction on hs_gemm.                                     */
 /* ------------------------------------------------------------------------------------------- */
-/* feat[b] = [SiLU(x[b,:]) | bases(x[b,0]) .. bases(x[b,in-1])], row length in*(1 + grid_size + order);
-   grid: (in, grid_size + 2*order + 1) knots. */
+/* feat[b] = [act(x[b,:]) | bases(x[b,0]) .. bases(x[b,in-1])], row length in*(1 + grid_size + order);
+   grid: (in, grid_size + 2*order + 1) knots.  base_act = the layer's `base_activation` (kan1.py:17,35): 0 SiLU (the
+   reference default), 1 GELU (erf), 2 ReLU, 3 identity -- the KAN classifier head (reference modules/heads.py:108-140,
+   `act_mode`) selects it. */
 hs_status hs_kan_features_fwd(const float* x, const float* grid, float* feat, int64_t B, int32_t in_f, int32_t grid_size,
-                              int32_t order, void* stream);
+                              int32_t order, int32_t base_act, void* stream);
 hs_status hs_kan_features_bwd(const float* x, const float* grid, const float* dfeat, float* dx, int64_t B, int32_t in_f,
-                              int32_t grid_size, int32_t order, void* stream);
+                              int32_t grid_size, int32_t order, int32_t base_act, void* stream);
 /* wcat[o] = [base_w[o,:] | spline_w[o,i,:]*scaler[o,i] ...]  (scaler may be NULL), nb = grid_size + order. */
 hs_status hs_kan_pack_weight(const float* base_w, const float* spline_w, const float* scaler, float* wcat, int32_t out_f,
                              int32_t in_f, int32_t nb, void* stream);

@@ -7,13 +7,19 @@ import torch
 from hamspine import kan as K
 
 
+# `base_activation` classes the feature kernel implements (hs_kan_features_*: base_act)
+_BASE_ACT_CODES = {torch.nn.SiLU: "silu", torch.nn.GELU: "gelu", torch.nn.ReLU: "relu", torch.nn.Identity: "identity"}
+
+
 class KANLinear(torch.nn.Module):
     def __init__(self, in_features, out_features, grid_size=5, spline_order=3, scale_noise=0.1, scale_base=1.0,
                  scale_spline=1.0, enable_standalone_scale_spline=True, base_activation=torch.nn.SiLU, grid_eps=0.02,
                  grid_range=[-1, 1]):
         super().__init__()
-        if base_activation is not torch.nn.SiLU:
-            raise NotImplementedError("only the SiLU base activation (the reference default) is implemented")
+        if base_activation not in _BASE_ACT_CODES:
+            raise NotImplementedError(f"base activation {base_activation!r}: the kernels implement "
+                                      f"{[c.__name__ for c in _BASE_ACT_CODES]}")
+        self._base_act = _BASE_ACT_CODES[base_activation]
         self.in_features, self.out_features = in_features, out_features
         self.grid_size, self.spline_order = grid_size, spline_order
         h = (grid_range[1] - grid_range[0]) / grid_size
@@ -65,7 +71,8 @@ class KANLinear(torch.nn.Module):
         if flat.dtype != torch.float32:
             flat = flat.float()
         scaler = self.spline_scaler if self.enable_standalone_scale_spline else None
-        out = K.kan_linear(flat, self.grid, self.base_weight, self.spline_weight, scaler, self.grid_size, self.spline_order)
+        out = K.kan_linear(flat, self.grid, self.base_weight, self.spline_weight, scaler, self.grid_size, self.spline_order,
+                           self._base_act)
         return out.reshape(*shape[:-1], self.out_features)
 
     def update_grid(self, x, margin=0.01):

@@ -644,19 +644,59 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
             }
     }
 }
-// scatter-add of token gradients into the word table (atomics: duplicates of an id collide)
+// Gradient of the word table, deterministic and atomics-free: one workgroup per token t.  The workgroup lists every token
+// that carries t's id, in token order (256 contiguous id chunks, ordered compaction through a block prefix sum); only the
+// FIRST occurrence of an id owns its table row, sums the listed dsum rows in that fixed order and stores the row once.
+// Duplicate ids (frequent in text) therefore add up in the same order on every run, whatever else shares the chip
+// (float atomics here made two runs of one step differ in their last bits).  Rows of ids that do not occur stay as the
+// caller zero-filled them; the pad row receives no gradient (nn.Embedding(padding_idx)).
+__device__ __forceinline__ long long clamp_id(long long id, int V) { return id < 0 ? 0 : (id >= V ? V - 1 : id); }
 template <typename T>
 __global__ __launch_bounds__(256) void embed_word_bwd_kernel(const long long* __restrict__ ids, const T* __restrict__ dsum,
-                                                             float* __restrict__ dword, long long tokens, int H, int V,
+                                                             float* __restrict__ dword, int tokens, int H, int V,
                                                              int pad_id) {
+    extern __shared__ __attribute__((aligned(16))) int s_mem[];   // [tokens] match list + [8] wave totals
+    int* s_list = s_mem;
+    int* s_wave = s_mem + tokens;
+    const int t = blockIdx.x;
+    const long long id = clamp_id(ids[t], V);
+    if (id == pad_id) return;                                     // block-uniform
+    const int per = (tokens + 255) / 256;
+    const int lo = min((int)threadIdx.x * per, tokens), hi = min(lo + per, tokens);
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += clamp_id(ids[i], V) == id ? 1 : 0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = c;                                                 // inclusive scan inside the wave
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    int off = incl - c;
+    for (int w = 0; w < wv; ++w) off += s_wave[w];
+    const int n = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    for (int i = lo; i < hi; ++i)
+        if (clamp_id(ids[i], V) == id) s_list[off++] = i;
+    __syncthreads();
+    if (s_list[0] != t) return;                                   // a smaller token index owns this id (block-uniform)
+    for (int h = threadIdx.x; h < H; h += 256) {
+        float acc = 0.f;
+        for (int k = 0; k < n; ++k) acc += to_f32(dsum[(long long)s_list[k] * H + h]);
+        dword[id * H + h] = acc;
+    }
+}
+// the same scatter with float atomics: only for token counts whose match list does not fit the LDS
+template <typename T>
+__global__ __launch_bounds__(256) void embed_word_bwd_atomic_kernel(const long long* __restrict__ ids,
+                                                                    const T* __restrict__ dsum, float* __restrict__ dword,
+                                                                    long long tokens, int H, int V, int pad_id) {
     const long long total = tokens * H;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long t = i / H;
         const int h = (int)(i % H);
-        long long id = ids[t];
-        if (id < 0) id = 0;
-        if (id >= V) id = V - 1;
-        if (id == pad_id) continue;   // nn.Embedding(padding_idx): the pad row receives no gradient
+        const long long id = clamp_id(ids[t], V);
+        if (id == pad_id) continue;
         atomicAdd(dword + id * H + h, to_f32(dsum[i]));
     }
 }
@@ -1121,11 +1161,19 @@ hs_status hs_bert_embed_bwd(int32_t dtype, const int64_t* ids, const void* dsum,
     hipStream_t s = (hipStream_t)stream;
     const long long tokens = (long long)B * L;
     if (dword) {   // caller zero-fills dword first
-        if (dtype == HS_BF16)
-            hipLaunchKernelGGL(embed_word_bwd_kernel<bf16_t>, dim3(grid_for(tokens * H)), dim3(256), 0, s,
+        const bool det = tokens <= 15360;                 // match list (4 B per token) + wave totals within 64 KiB of LDS
+        const size_t lds = det ? (size_t)(tokens + 8) * sizeof(int) : 0;
+        if (det && dtype == HS_BF16)
+            hipLaunchKernelGGL(embed_word_bwd_kernel<bf16_t>, dim3((unsigned)tokens), dim3(256), lds, s, (const long long*)ids,
+                               (const bf16_t*)dsum, dword, (int)tokens, H, V, pad_id);
+        else if (det)
+            hipLaunchKernelGGL(embed_word_bwd_kernel<float>, dim3((unsigned)tokens), dim3(256), lds, s, (const long long*)ids,
+                               (const float*)dsum, dword, (int)tokens, H, V, pad_id);
+        else if (dtype == HS_BF16)
+            hipLaunchKernelGGL(embed_word_bwd_atomic_kernel<bf16_t>, dim3(grid_for(tokens * H)), dim3(256), 0, s,
                                (const long long*)ids, (const bf16_t*)dsum, dword, tokens, H, V, pad_id);
         else
-            hipLaunchKernelGGL(embed_word_bwd_kernel<float>, dim3(grid_for(tokens * H)), dim3(256), 0, s,
+            hipLaunchKernelGGL(embed_word_bwd_atomic_kernel<float>, dim3(grid_for(tokens * H)), dim3(256), 0, s,
                                (const long long*)ids, (const float*)dsum, dword, tokens, H, V, pad_id);
         HS_LAUNCH_CHECK();
     }

@@ -35,9 +35,33 @@ __device__ __forceinline__ void bspline_eval(float x, const float* __restrict__ 
     }
 }
 
-// feat[b] = [ SiLU(x[b, :]) | bases(x[b, 0]) ... bases(x[b, in-1]) ]   (row length in*(1+nb))
+// base activation of the layer (kan1.py:17 `base_activation`, SiLU by default; the KAN classifier head of
+// modules/heads.py:108-140 selects it with `act_mode`): value and derivative
+enum { KAN_ACT_SILU = 0, KAN_ACT_GELU = 1, KAN_ACT_RELU = 2, KAN_ACT_IDENTITY = 3 };
+__device__ __forceinline__ float kan_act(float x, int act) {
+    switch (act) {
+        case KAN_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+        case KAN_ACT_RELU: return x > 0.f ? x : 0.f;
+        case KAN_ACT_IDENTITY: return x;
+        default: return x / (1.f + __expf(-x));
+    }
+}
+__device__ __forceinline__ float kan_act_grad(float x, int act) {
+    switch (act) {
+        case KAN_ACT_GELU:
+            return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+        case KAN_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        case KAN_ACT_IDENTITY: return 1.f;
+        default: {
+            const float sg = 1.f / (1.f + __expf(-x));
+            return sg * (1.f + x * (1.f - sg));
+        }
+    }
+}
+
+// feat[b] = [ act(x[b, :]) | bases(x[b, 0]) ... bases(x[b, in-1]) ]   (row length in*(1+nb))
 __global__ void kan_features_kernel(const float* __restrict__ x, const float* __restrict__ grid, float* __restrict__ feat,
-                                    long long B, int in_f, int nk, int order) {
+                                    long long B, int in_f, int nk, int order, int act) {
     const int nb = nk - 1 - order;
     const long long total = B * in_f;
     const int row = in_f * (1 + nb);
@@ -48,14 +72,14 @@ __global__ void kan_features_kernel(const float* __restrict__ x, const float* __
         float Bv[KAN_MAXK], dBv[KAN_MAXK];
         bspline_eval(xv, grid + (long long)i * nk, nk, order, Bv, dBv);
         float* o = feat + b * row;
-        o[i] = xv / (1.f + __expf(-xv));
+        o[i] = kan_act(xv, act);
         for (int j = 0; j < nb; ++j) o[in_f + i * nb + j] = Bv[j];
     }
 }
-// dx[b,i] = dfeat[b,i]*SiLU'(x) + sum_j dfeat[b, in + i*nb + j] * dB_j/dx
+// dx[b,i] = dfeat[b,i]*act'(x) + sum_j dfeat[b, in + i*nb + j] * dB_j/dx
 __global__ void kan_features_bwd_kernel(const float* __restrict__ x, const float* __restrict__ grid,
                                         const float* __restrict__ dfeat, float* __restrict__ dx, long long B, int in_f,
-                                        int nk, int order) {
+                                        int nk, int order, int act) {
     const int nb = nk - 1 - order;
     const long long total = B * in_f;
     const int row = in_f * (1 + nb);
@@ -66,8 +90,7 @@ __global__ void kan_features_bwd_kernel(const float* __restrict__ x, const float
         float Bv[KAN_MAXK], dBv[KAN_MAXK];
         bspline_eval(xv, grid + (long long)i * nk, nk, order, Bv, dBv);
         const float* g = dfeat + b * row;
-        const float sg = 1.f / (1.f + __expf(-xv));
-        float acc = g[i] * sg * (1.f + xv * (1.f - sg));
+        float acc = g[i] * kan_act_grad(xv, act);
         for (int j = 0; j < nb; ++j) acc += g[in_f + i * nb + j] * dBv[j];
         dx[t] = acc;
     }
@@ -442,20 +465,22 @@ using namespace hs;
 
 extern "C" {
 hs_status hs_kan_features_fwd(const float* x, const float* grid, float* feat, int64_t B, int32_t in_f, int32_t grid_size,
-                              int32_t order, void* stream) {
+                              int32_t order, int32_t base_act, void* stream) {
     const int nk = grid_size + 2 * order + 1;
     HS_REQUIRE(x && grid && feat && nk <= KAN_MAXK && order >= 0, "kan_features: bad argument");
+    HS_REQUIRE(base_act >= KAN_ACT_SILU && base_act <= KAN_ACT_IDENTITY, "kan_features: unknown base activation %d", base_act);
     hipLaunchKernelGGL(kan_features_kernel, dim3(grid_for(B * in_f)), dim3(256), 0, (hipStream_t)stream, x, grid, feat,
-                       (long long)B, in_f, nk, order);
+                       (long long)B, in_f, nk, order, base_act);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
 hs_status hs_kan_features_bwd(const float* x, const float* grid, const float* dfeat, float* dx, int64_t B, int32_t in_f,
-                              int32_t grid_size, int32_t order, void* stream) {
+                              int32_t grid_size, int32_t order, int32_t base_act, void* stream) {
     const int nk = grid_size + 2 * order + 1;
     HS_REQUIRE(x && grid && dfeat && dx && nk <= KAN_MAXK, "kan_features_bwd: bad argument");
+    HS_REQUIRE(base_act >= KAN_ACT_SILU && base_act <= KAN_ACT_IDENTITY, "kan_features_bwd: unknown base activation %d", base_act);
     hipLaunchKernelGGL(kan_features_bwd_kernel, dim3(grid_for(B * in_f)), dim3(256), 0, (hipStream_t)stream, x, grid, dfeat,
-                       dx, (long long)B, in_f, nk, order);
+                       dx, (long long)B, in_f, nk, order, base_act);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }

@@ -19,8 +19,8 @@ def _l():
     global _declared
     l = L.lib()
     if not _declared:
-        l.hs_kan_features_fwd.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp]
-        l.hs_kan_features_bwd.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, vp]
+        l.hs_kan_features_fwd.argtypes = [vp, vp, vp, i64, i32, i32, i32, i32, vp]
+        l.hs_kan_features_bwd.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
         l.hs_kan_pack_weight.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
         l.hs_kan_unpack_wgrad.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
         l.hs_moe_gate_fwd.argtypes = [vp, vp, i32, i32, i32, i32, f32, u64, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -43,9 +43,12 @@ def _f32c(t):
     return t.contiguous()
 
 
+BASE_ACTS = {"silu": 0, "swish": 0, "gelu": 1, "relu": 2, "identity": 3}   # hs_kan_features_* base_act codes
+
+
 class KANLinearFn(Function):
     @staticmethod
-    def forward(ctx, x, grid, base_w, spline_w, scaler, grid_size, order):
+    def forward(ctx, x, grid, base_w, spline_w, scaler, grid_size, order, act=0):
         x, base_w, spline_w = _f32c(x), _f32c(base_w), _f32c(spline_w)
         grid = _f32c(grid)
         scaler = _f32c(scaler) if scaler is not None else None
@@ -57,19 +60,20 @@ class KANLinearFn(Function):
         lib = _l()
         feat = torch.empty((B, Kc), dtype=torch.float32, device=dev)
         wcat = torch.empty((out_f, Kc), dtype=torch.float32, device=dev)
-        L.check(lib.hs_kan_features_fwd(rt.p(x), rt.p(grid), rt.p(feat), B, in_f, grid_size, order, rt.stream()), "kan_features")
+        L.check(lib.hs_kan_features_fwd(rt.p(x), rt.p(grid), rt.p(feat), B, in_f, grid_size, order, act, rt.stream()),
+                "kan_features")
         L.check(lib.hs_kan_pack_weight(rt.p(base_w), rt.p(spline_w), rt.p(scaler), rt.p(wcat), out_f, in_f, nb, rt.stream()),
                 "kan_pack_weight")
         y = torch.empty((B, out_f), dtype=torch.float32, device=dev)
         raw.gemm(feat, wcat, y, B, out_f, Kc, lda=Kc, ldb=Kc)
         ctx.save_for_backward(x, grid, spline_w, scaler, feat, wcat)
-        ctx.meta = (grid_size, order, base_w.shape)
+        ctx.meta = (grid_size, order, base_w.shape, act)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, grid, spline_w, scaler, feat, wcat = ctx.saved_tensors
-        grid_size, order, base_shape = ctx.meta
+        grid_size, order, base_shape, act = ctx.meta
         dy = _f32c(dy)
         B, in_f = x.shape
         out_f = base_shape[0]
@@ -93,13 +97,14 @@ class KANLinearFn(Function):
             dfeat = torch.empty((B, Kc), dtype=torch.float32, device=dev)
             raw.gemm(dy, wcat, dfeat, B, Kc, out_f, a_kind=L.A_KC, b_kind=L.B_RC, lda=out_f, ldb=Kc)
             dx = torch.empty_like(x)
-            L.check(lib.hs_kan_features_bwd(rt.p(x), rt.p(grid), rt.p(dfeat), rt.p(dx), B, in_f, grid_size, order, rt.stream()),
-                    "kan_features_bwd")
-        return dx, None, d_base, d_spline, d_scaler, None, None
+            L.check(lib.hs_kan_features_bwd(rt.p(x), rt.p(grid), rt.p(dfeat), rt.p(dx), B, in_f, grid_size, order, act,
+                                            rt.stream()), "kan_features_bwd")
+        return dx, None, d_base, d_spline, d_scaler, None, None, None
 
 
-def kan_linear(x, grid, base_weight, spline_weight, spline_scaler, grid_size, spline_order):
-    return KANLinearFn.apply(x, grid, base_weight, spline_weight, spline_scaler, int(grid_size), int(spline_order))
+def kan_linear(x, grid, base_weight, spline_weight, spline_scaler, grid_size, spline_order, base_act="silu"):
+    return KANLinearFn.apply(x, grid, base_weight, spline_weight, spline_scaler, int(grid_size), int(spline_order),
+                             BASE_ACTS[base_act])
 
 
 class MoEGateFn(Function):

@@ -25,15 +25,9 @@ class _FusedAdamBase(torch.optim.Optimizer):
         (scripts/train.py:373-385, mibf_net/train_resnet.py:29-33)."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._overlap = bool(overlap_backward)
-        if self._overlap:
-            # KNOWN ISSUE (end of round 1): this optional mode is validated with the composites' weight-gradient side stream
-            # on.  With the side stream off (the default since the GEMM epilogue work) the update of the last gradients of
-            # backward (the stem) can come out wrong (tests/test_product_gpu.py::test_optimizer_in_backward..., cause not yet
-            # found).  The mode measured neutral-to-worse in both configurations and nothing uses it by default, so it
-            # switches the side stream back on for the process.
-            L.lib().hs_set_overlap(1)
         self._chunk = int(overlap_chunk)
         self._pending, self._pending_n = [], 0
+        self._pending_streams = {}      # streams the pending gradients became final on (id -> torch.cuda.Stream)
         self._stream = None
         self._done = set()
         if self._overlap:
@@ -45,8 +39,17 @@ class _FusedAdamBase(torch.optim.Optimizer):
 
     # -- optimizer-in-backward -------------------------------------------------------------------------------------
     def _on_grad(self, p):
-        self._pending.append(p)
-        self._pending_n += p.numel()
+        """post-accumulate hook: runs on the autograd thread with the AccumulateGrad node's stream current; the engine
+        has already ordered that stream behind the node that produced the gradient."""
+        if p in self._done:
+            raise RuntimeError(
+                "FusedAdam(overlap_backward=True): a parameter received a second gradient after its update was enqueued "
+                "(a second backward() before step(): gradient accumulation) -- step after backward instead")
+        s = torch.cuda.current_stream(p.device)
+        self._pending_streams[s.cuda_stream] = s
+        if not any(q is p for q in self._pending):
+            self._pending.append(p)
+            self._pending_n += p.numel()
         if self._pending_n >= self._chunk or len(self._pending) >= 96:
             self._flush()
 
@@ -58,11 +61,16 @@ class _FusedAdamBase(torch.optim.Optimizer):
         dev = ps[0].device
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=dev)
+        # Order the update behind EVERY stream a pending gradient became final on -- not only the stream of the hook that
+        # happens to trigger the flush.  (Round-1 bug: the image tower's backward runs first, on the ambient stream; the
+        # stem's small gradients stayed pending below the chunk size and were flushed later from a BERT parameter's hook,
+        # whose current stream is the text tower's: the update then waited for the tower stream only and could read the
+        # stem's weight gradient before its GEMM had finished.)
+        streams, self._pending_streams = self._pending_streams, {}
         cur = torch.cuda.current_stream(dev)
-        self._stream.wait_stream(cur)                       # gradients may come from the ambient or a tower stream
-        for s in rt.side_streams():
-            if s.device == dev and s != cur:
-                self._stream.wait_stream(s)
+        streams[cur.cuda_stream] = cur
+        for s in streams.values():
+            self._stream.wait_stream(s)
         with torch.cuda.stream(self._stream):
             by_group = {}
             for p in ps:

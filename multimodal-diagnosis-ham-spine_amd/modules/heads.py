@@ -4,8 +4,38 @@ import torch.nn as nn
 
 from hamspine import functional as F
 from hamspine.nn import LayerNorm, Linear, MultiheadAttention
+from hamspine.nn.layers import Dropout
 
-GroupKANLinear = None   # the reference resolves this from the external `ikan` package (heads.py:7-25)
+from ConNexT.models.block.kan1 import KANLinear
+
+_KAN_ACTS = {"gelu": nn.GELU, "silu": nn.SiLU, "swish": nn.SiLU, "relu": nn.ReLU, "identity": nn.Identity}
+
+
+class GroupKANLinear(KANLinear):
+    """Stand-in for `ikan.GroupKAN.GroupKANLinear`, which the reference imports from an external package whose source
+    is not in the reference tree (heads.py:7-25), so its arithmetic cannot be restated or pinned.
+
+    DEVIATION: the layer follows the reference's own in-tree KAN layer instead --
+    `ConNexT/models/block/kan1.py:77-165` KANLinear (B-spline edges on a 5-interval grid, order 3, plus a base path
+    `base_weight @ act(x)`) -- with the constructor surface `build_kan_head` uses (heads.py:125-139):
+      * act_mode  -> the layer's `base_activation` (gelu | silu/swish | relu | identity),
+      * drop      -> dropout on the layer input (train mode only),
+      * num_groups-> validated (must divide in_features, as heads.py:119-122 does) and kept; the in-tree layer has one
+                     spline per edge, so there is nothing for groups to share and the value does not change the result.
+    Parameters / state-dict keys are KANLinear's (base_weight, spline_weight, spline_scaler, grid).  A checkpoint
+    trained with the ikan layer cannot be loaded (different parameterisation)."""
+
+    def __init__(self, in_features, out_features, act_mode="gelu", drop=0.0, num_groups=8, bias=True):
+        if act_mode not in _KAN_ACTS:
+            raise ValueError(f"act_mode must be one of {sorted(_KAN_ACTS)}, got {act_mode!r}")
+        if in_features % num_groups != 0:
+            raise ValueError(f"num_groups ({num_groups}) must divide in_features ({in_features}).")
+        super().__init__(in_features, out_features, base_activation=_KAN_ACTS[act_mode])
+        self.act_mode, self.num_groups = act_mode, num_groups
+        self.drop = Dropout(drop)
+
+    def forward(self, x):
+        return super().forward(self.drop(_f32(x)))
 
 
 def _f32(x):
@@ -62,13 +92,15 @@ class AttentionPoolingClassifier(nn.Module):
 
 
 def build_kan_head(hidden_dim, num_classes, dropout=0.1, num_groups=8, act_mode="gelu"):
-    """The reference builds this head from `ikan.GroupKAN.GroupKANLinear`, whose source is not in the reference
-    tree (heads.py:7-25,108-140).  Same behaviour when the package is absent: ImportError."""
-    if GroupKANLinear is None:
-        raise ImportError("GroupKANLinear not found. Install the ikan package to use classifier_type='kan'.")
+    """GroupKANLinear(H, H) -> LayerNorm(H) -> GroupKANLinear(H, C), the reference's structure (heads.py:108-140)
+    on the stand-in layer above (see its DEVIATION note)."""
     if hidden_dim % num_groups != 0:
         raise ValueError(f"kan_num_groups ({num_groups}) must divide hidden_dim ({hidden_dim}).")
-    raise ImportError("GroupKANLinear has no hamspine implementation")
+    return nn.Sequential(
+        GroupKANLinear(hidden_dim, hidden_dim, act_mode=act_mode, drop=dropout, num_groups=num_groups),
+        LayerNorm(hidden_dim),
+        GroupKANLinear(hidden_dim, num_classes, act_mode=act_mode, drop=0.0, num_groups=num_groups),
+    )
 
 
 __all__ = ["ResidualClassifier", "AttentionPoolingClassifier", "build_kan_head"]

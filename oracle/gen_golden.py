@@ -164,6 +164,79 @@ def gen_kan_moe():
          gw={k: p.grad for k, p in m.named_parameters() if p.grad is not None})
 
 
+def install_kan_head_standin():
+    """`ikan.GroupKAN.GroupKANLinear` is an external package absent from the reference tree and from this container
+    (modules/heads.py:7-25 resolves it to None and build_kan_head raises).  For the classifier_type="kan" vectors the
+    reference's OWN in-tree KAN layer (ConNexT/models/block/kan1.py KANLinear) is put in its place with the constructor
+    surface build_kan_head uses: act_mode -> base_activation, drop -> input dropout, num_groups validated only.
+    Everything else that runs (build_kan_head's Sequential, model.py's wiring, KANLinear's arithmetic) is the reference's."""
+    from ConNexT.models.block import kan1
+    from modules import heads
+    acts = {"gelu": torch.nn.GELU, "silu": torch.nn.SiLU, "swish": torch.nn.SiLU, "relu": torch.nn.ReLU,
+            "identity": torch.nn.Identity}
+
+    class GroupKANLinear(kan1.KANLinear):
+        def __init__(self, in_features, out_features, act_mode="gelu", drop=0.0, num_groups=8):
+            if in_features % num_groups != 0:
+                raise ValueError("num_groups must divide in_features")
+            super().__init__(in_features, out_features, base_activation=acts[act_mode])
+            self.drop = torch.nn.Dropout(drop)
+
+        def forward(self, x):
+            return super().forward(self.drop(x))
+    heads.GroupKANLinear = GroupKANLinear
+    import model as ref_model
+    assert ref_model.build_kan_head is heads.build_kan_head
+
+
+def gen_kan_head(tmp):
+    from ConNexT.models.block import kan1
+    from modules import heads
+    install_kan_head_standin()
+    x = rnd((6, 64), 55, 0.7)
+    run_case("kan_linear_gelu", kan1.KANLinear(16, 12, base_activation=torch.nn.GELU), dict(x=rnd((6, 16), 51, 0.7)), SEED + 84)
+    run_case("head_kan", heads.build_kan_head(64, 7, dropout=0.0, num_groups=8, act_mode="gelu"), dict(input=x), SEED + 85)
+    run_case("head_kan_silu", heads.build_kan_head(64, 7, dropout=0.0, num_groups=4, act_mode="silu"), dict(input=x), SEED + 86)
+
+
+def install_train_script_standins():
+    """scripts/train.py imports torch.utils.tensorboard (absent) and data_loader (needs PIL/cv2/torchvision.transforms)
+    at module level (train.py:12,21); neither is touched by SupConLoss / FocalLoss (train.py:23-61).  Empty stand-ins
+    make the module importable so that the two loss classes that run are the reference's own."""
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = type("SummaryWriter", (), {})
+    sys.modules.setdefault("torch.utils.tensorboard", tb)
+    dl = types.ModuleType("data_loader")
+    dl.create_data_loader = None
+    sys.modules.setdefault("data_loader", dl)
+
+
+def gen_losses(tmp):
+    """G9: FocalLoss / SupConLoss of scripts/train.py:23-61 and CE(label_smoothing=0.02, class weights) of train.py:240-254"""
+    install_train_script_standins()
+    from scripts import train as ref_train
+    B, Cn, D = 12, 7, 32
+    labels = torch.tensor([0, 3, 3, 1, 6, 0, 2, 3, 5, 1, 1, 4])
+    weight = 0.5 + torch.rand(Cn, generator=torch.Generator().manual_seed(91))
+    for name, gamma, w in (("focal_g2", 2.0, None), ("focal_g1p5_weighted", 1.5, weight)):
+        logits = rnd((B, Cn), 92, 2.0).requires_grad_(True)
+        loss = ref_train.FocalLoss(gamma=gamma, weight=w)(logits, labels)
+        loss.backward()
+        save(name, logits=logits.detach(), labels=labels, weight=w if w is not None else torch.zeros(0), gamma=gamma,
+             loss=loss.detach(), dlogits=logits.grad)
+    for name, temp, lab in (("supcon_t007", 0.07, labels), ("supcon_t05_singletons", 0.5, torch.tensor([0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 3]))):
+        feat = rnd((B, D), 93).requires_grad_(True)
+        loss = ref_train.SupConLoss(temperature=temp)(feat, lab)
+        loss.backward()
+        save(name, features=feat.detach(), labels=lab, temperature=temp, loss=loss.detach(), dfeatures=feat.grad)
+    for name, sm, w in (("ce_smooth002", 0.02, None), ("ce_smooth002_weighted", 0.02, weight)):
+        logits = rnd((B, Cn), 94, 2.0).requires_grad_(True)
+        loss = torch.nn.CrossEntropyLoss(weight=w, label_smoothing=sm)(logits, labels)
+        loss.backward()
+        save(name, logits=logits.detach(), labels=labels, weight=w if w is not None else torch.zeros(0), smoothing=sm,
+             loss=loss.detach(), dlogits=logits.grad)
+
+
 def save_tiny_bert(cfg, tmp):
     from transformers import BertConfig, BertModel
     d = os.path.join(tmp, f"bert_{cfg['hidden_size']}_{cfg['num_hidden_layers']}")
@@ -222,9 +295,19 @@ def gen_e2e_baseline(tmp):
                                          sequence_type="transformer", sequence_hidden_dim=32, sequence_num_layers=2,
                                          sequence_dropout=0.0, sequence_num_heads=4),
     }
+    # BASELINE config 5: hierarchical multiscale fusion + global-local dual stream + dual-expert gate + KAN head
+    # (reference configs: fusion_type multiscale, global_local.enabled, gate.enabled, classifier_type kan); the KAN
+    # layer is the stand-in of install_kan_head_standin (external ikan package absent)
+    install_kan_head_standin()
+    cases["e2e_c5_multiscale_gl_gate_kan"] = dict(fusion_type="multiscale", classifier_type="kan", kan_num_groups=8,
+                                                  kan_act_mode="gelu", gate_enabled=True, gate_hidden_dim=32,
+                                                  global_local_enabled=True, global_local_crop_ratio=0.6)
+    only = os.environ.get("GEN_E2E_ONLY")            # regenerate a single case without touching the others
     seq_images = rnd((2, 3, 3, 64, 64), 83)
     crit = torch.nn.CrossEntropyLoss(label_smoothing=0.02)
     for i, (name, kw) in enumerate(cases.items()):
+        if only and name != only:
+            continue
         m = ref_model.MultimodalBaselineModel(**common, **kw)
         load_procedural(m, SEED + 100 + i)
         m.train()
@@ -312,7 +395,8 @@ def main():
     install_torchvision_standin()
     sys.path.insert(0, REF)
     groups = {"fusion": lambda tmp: gen_fusion(), "heads": lambda tmp: gen_heads(), "ibfa": lambda tmp: gen_ibfa(),
-              "kan_moe": lambda tmp: gen_kan_moe(), "bert": gen_bert, "e2e_baseline": gen_e2e_baseline,
+              "kan_moe": lambda tmp: gen_kan_moe(), "kan_head": gen_kan_head, "losses": gen_losses, "bert": gen_bert,
+              "e2e_baseline": gen_e2e_baseline,
               "e2e_mibf": gen_e2e_mibf, "convnext": gen_convnext}
     want = sys.argv[1:] or list(groups)          # optional: regenerate only the named groups
     with tempfile.TemporaryDirectory() as tmp:

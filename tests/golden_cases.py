@@ -87,6 +87,16 @@ MODULE_CASES = {
 }
 
 MODULE_CASES["kan_linear"] = (SEED + 80, lambda: _o().OKANLinear(16, 12), lambda: _kan().KANLinear(16, 12), call_kwargs)
+MODULE_CASES["kan_linear_gelu"] = (SEED + 84, lambda: _o().OKANLinear(16, 12, base_activation=torch.nn.GELU),
+                                   lambda: _kan().KANLinear(16, 12, base_activation=torch.nn.GELU), call_kwargs)
+# classifier_type="kan" head: reference modules/heads.py:108-140 run with its in-tree KANLinear in place of the
+# absent external ikan layer (oracle/gen_golden.py: install_kan_head_standin)
+MODULE_CASES["head_kan"] = (SEED + 85, lambda: _o().okan_head(H, 7, 0.0, 8, "gelu"),
+                            lambda: _p()[2].build_kan_head(H, 7, dropout=0.0, num_groups=8, act_mode="gelu"),
+                            lambda m, inp: m(inp["input"]))
+MODULE_CASES["head_kan_silu"] = (SEED + 86, lambda: _o().okan_head(H, 7, 0.0, 4, "silu"),
+                                 lambda: _p()[2].build_kan_head(H, 7, dropout=0.0, num_groups=4, act_mode="silu"),
+                                 lambda m, inp: m(inp["input"]))
 MODULE_CASES["kan1_stack"] = (SEED + 81, lambda: _o().OKAN1([16, 24, 8]), lambda: _kan().KAN1([16, 24, 8]), call_kwargs)
 
 _KINDS = {"concat": ("OConcatFusion", "ConcatFusionModule"), "weighted_concat": ("OWeightedConcatFusion", "WeightedConcatFusionModule"),
@@ -123,7 +133,13 @@ E2E_CASES = {
     "e2e_sequence_transformer": (SEED + 109, dict(fusion_type="multiscale", classifier_type="mlp", sequence_enabled=True,
                                                   sequence_type="transformer", sequence_hidden_dim=32,
                                                   sequence_num_layers=2, sequence_dropout=0.0, sequence_num_heads=4)),
+    # BASELINE config 5: hierarchical multiscale fusion + global-local dual stream + dual-expert gate + KAN head
+    "e2e_c5_multiscale_gl_gate_kan": (SEED + 110, dict(fusion_type="multiscale", classifier_type="kan", kan_num_groups=8,
+                                                       kan_act_mode="gelu", gate_enabled=True, gate_hidden_dim=32,
+                                                       global_local_enabled=True, global_local_crop_ratio=0.6)),
 }
+LOSS_CASES = ("focal_g2", "focal_g1p5_weighted", "supcon_t007", "supcon_t05_singletons", "ce_smooth002",
+              "ce_smooth002_weighted")
 
 
 def e2e_inputs(kw=None):

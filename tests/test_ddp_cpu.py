@@ -66,6 +66,24 @@ def _worker(rank, world, port, out):
         # parameters stay identical across ranks after synchronous steps
         dist.all_gather(w, net.a.weight.data)
         assert all(torch.allclose(w[0], t) for t in w)
+        # one big bucket that holds the never-used parameter: the first step learns the unused set (bucket reduced in
+        # finish()), from the second step on the bucket completes -- and launches -- during backward
+        net2 = _Net()
+        big = DataParallel(net2, bucket_mb=128)
+        assert len(big.buckets) == 1
+        for step in range(3):
+            x = torch.randn(6, 16, generator=torch.Generator().manual_seed(50 + 7 * step + rank))
+            ref = _Net()
+            ref.load_state_dict(net2.state_dict())
+            ref(x).square().sum().backward()
+            big.zero_grad()
+            big(x).square().sum().backward()
+            big.finish()
+            assert net2.unused.weight.grad is None
+            g = [torch.empty_like(ref.a.weight.grad) for _ in range(world)]
+            dist.all_gather(g, ref.a.weight.grad)
+            assert torch.allclose(net2.a.weight.grad, sum(g) / world, rtol=1e-5, atol=1e-6), f"big bucket step {step}"
+            assert big.stats == {"launched_in_backward": step, "launched_in_finish": 1}, (step, big.stats)
         out.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         out.put((rank, repr(e)))

@@ -126,3 +126,109 @@ def test_two_ranks_on_one_card_average_gradients(tmp_path):
         assert err <= 2e-5 * scale + 1e-7, f"{k}: averaged gradient {err:.3e} off the mean of the local ones (scale {scale:.3e})"
     for k, g in g0.items():
         assert torch.isfinite(g).all(), k
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The reference's own wrapping (mibf_net/train_resnet.py:134): torch DistributedDataParallel(find_unused_parameters=True)
+# around the product Resnet50WithOurs, `model(batch)` through the wrapper and `cal_loss` on the unwrapped module (:23,30-31)
+# ----------------------------------------------------------------------------------------------------------------------
+def _mibf_build(tmp, rank_seed=None):
+    from mibf_net.model_resnet import Resnet50WithOurs
+    from oracle.procedural import load_procedural
+    d = gc.save_bert_dir(gc.MIBF_BERT, os.path.join(tmp, "bert768"))
+    m = Resnet50WithOurs(num_labels=6, loss_class="KL_loss", bert_path=d)
+    load_procedural(m, gc.SEED + 200 if rank_seed is None else rank_seed)
+    return m.to("cuda").train()
+
+
+def _mibf_batch(rank):
+    from oracle.procedural import synthetic_batch
+    images, ids, mask, labels = synthetic_batch(4, 64, 16, gc.MIBF_BERT["vocab_size"], 6, seed=700 + rank, min_len=3)
+    return {"input_ids": ids.cuda(), "attention_mask": mask.cuda(), "transformed_image": images.cuda()}, labels.cuda()
+
+
+def _torch_ddp_worker(rank, world, port, tmp, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, os.path.join(ROOT, "multimodal-diagnosis-ham-spine_amd"))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import hamspine
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        hamspine.set_compute_dtype("f32")
+        # rank 1 starts from DIFFERENT weights and buffers: the DDP constructor must make it follow rank 0
+        net = _mibf_build(os.path.join(tmp, f"t{rank}"), None if rank == 0 else 999)
+        model = DDP(net, device_ids=[0], find_unused_parameters=True)          # reference train_resnet.py:134
+        base_model = model.module                                               # train_resnet.py:23
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)                     # train_resnet.py:137 (torch.optim, unchanged)
+        batch, labels = _mibf_batch(rank)
+        first = None
+        for it in range(2):
+            if it == 1 and rank == 1:                                            # buffers must follow rank 0 at EVERY forward
+                with torch.no_grad():
+                    net.image_encoder.bn1.running_mean.add_(5.0)
+            opt.zero_grad()
+            outputs = model(batch)                                              # train_resnet.py:30
+            loss = base_model.cal_loss(outputs, labels)                         # :31
+            loss.backward()                                                     # :32
+            grads = {k: p.grad.detach().float().cpu().clone() for k, p in net.named_parameters() if p.grad is not None}
+            if it == 0:
+                first = grads
+            opt.step()
+        torch.cuda.synchronize()
+        nograd = sorted(k for k, p in net.named_parameters() if p.grad is None)
+        params = {k: p.detach().float().cpu().numpy() for k, p in net.named_parameters()}
+        rm = net.image_encoder.bn1.running_mean.detach().cpu().numpy()
+        out.put((rank, "ok", {k: v.numpy() for k, v in first.items()}, params, nograd, rm))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        out.put((rank, "error: " + repr(e) + traceback.format_exc(), None, None, None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reference_torch_ddp_wrapping_two_ranks(tmp_path):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_torch_ddp_worker, args=(r, 2, port, str(tmp_path), out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r = out.get(timeout=900)
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=120)
+    for r in res.values():
+        assert r[1] == "ok", r[1]
+    # never-called modules keep grad None on every rank (find_unused_parameters semantics)
+    assert res[0][4] == res[1][4]
+    assert any(k.startswith("I2Iattention") for k in res[0][4]) and any("pooler" in k for k in res[0][4])
+    assert all(k.startswith("I2Iattention") or "pooler" in k for k in res[0][4]), res[0][4]
+    # identical parameters on both ranks after two synchronous steps, although rank 1 was built from other weights
+    for k in res[0][3]:
+        assert (res[0][3][k] == res[1][3][k]).all(), f"parameters diverged: {k}"
+    # buffers follow rank 0 at every forward: rank 1's +5.0 on bn1.running_mean was overwritten before the second forward
+    assert abs(res[1][5] - res[0][5]).max() < 1.0, abs(res[1][5] - res[0][5]).max()
+    # step-1 gradients == mean of the two local gradients (single process, rank-0 weights, each rank's batch)
+    import hamspine
+    hamspine.set_compute_dtype("f32")
+    try:
+        local = []
+        for rank in range(2):
+            net = _mibf_build(str(tmp_path / f"u{rank}"))
+            batch, labels = _mibf_batch(rank)
+            net.cal_loss(net(batch), labels).backward()
+            local.append({k: p.grad.detach().float().cpu() for k, p in net.named_parameters() if p.grad is not None})
+    finally:
+        hamspine.set_compute_dtype("bf16")
+    for rk in range(2):
+        first = {k: torch.from_numpy(v) for k, v in res[rk][2].items()}
+        assert local[0].keys() == first.keys()
+        for k in first:
+            want = 0.5 * (local[0][k] + local[1][k])
+            scale = max(want.abs().max().item(), 1e-6)
+            err = (first[k] - want).abs().max().item()
+            assert err <= 2e-5 * scale + 1e-7, f"rank {rk} {k}: DDP gradient {err:.3e} off the mean of the local ones (scale {scale:.3e})"

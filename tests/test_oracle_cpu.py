@@ -200,6 +200,28 @@ def test_resnet_known_answers():
     assert sum(p.numel() for p in r50.parameters()) == 25081664
 
 
+@pytest.mark.parametrize("name", gc.LOSS_CASES)
+def test_oracle_losses_match_reference_vectors(name):
+    """G9: vectors made by the reference's own FocalLoss / SupConLoss (scripts/train.py:23-61) and CE"""
+    fx = gc.load(name)
+    if name.startswith("supcon"):
+        f = fx["features"].clone().requires_grad_(True)
+        loss = om.osupcon(f, fx["labels"], float(fx["temperature"]))
+        loss.backward()
+        _close(loss, fx["loss"], f"{name}: loss")
+        _close(f.grad, fx["dfeatures"], f"{name}: dfeatures", rtol=1e-4)
+        return
+    z = fx["logits"].clone().requires_grad_(True)
+    w = fx["weight"] if fx["weight"].numel() else None
+    if name.startswith("focal"):
+        loss = om.ofocal(z, fx["labels"], gamma=float(fx["gamma"]), weight=w)
+    else:
+        loss = torch.nn.functional.cross_entropy(z, fx["labels"], weight=w, label_smoothing=float(fx["smoothing"]))
+    loss.backward()
+    _close(loss, fx["loss"], f"{name}: loss")
+    _close(z.grad, fx["dlogits"], f"{name}: dlogits", rtol=1e-4)
+
+
 def test_focal_and_supcon_basics():
     z = torch.randn(8, 7, generator=torch.Generator().manual_seed(3))
     y = torch.randint(0, 7, (8,), generator=torch.Generator().manual_seed(4))
