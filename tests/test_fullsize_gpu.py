@@ -7,11 +7,22 @@ Bounds (f32 mode):
   logits      |err| <= 1e-4 * max|ref|          (BASELINE north_star: "logits within 1e-4 rel of the CPU reference")
   loss        1e-4 relative
   argmax      bit-exact class indices
-  gradients   every parameter, relative L2 error of the whole tensor <= GRAD_TOL (f32 summation-order noise through
-              53 BatchNorm layers / 12 BERT layers; the worst tensors are printed) and gradient norms to the same bound;
-              parameters the reference leaves without gradient (BERT pooler, I2Iattention) have grad None.
+  gradients   every parameter tensor, relative L2 error:
+                * text tower, fusion, heads (no ReLU / max-pool decisions below them):  <= 2e-4 against the CPU f32 values
+                * image tower: measured against an f64 evaluation of the oracle, the product may be at most
+                  GAP_FACTOR x as far from it as the reference-style CPU f32 evaluation itself is (+ 1e-4).
+                  Why not a flat bound: a ReLU / max-pool DECISION that flips between two evaluations (an activation
+                  within f32 rounding of zero) switches that element's gradient on or off; a fraction f of flipped
+                  elements moves a layer's gradient by ~sqrt(f) in relative L2 (f ~ 1e-5 -> 3e-3 per layer, ~2e-2 after
+                  the 49 ReLU layers of ResNet50).  The test PROVES that this is the whole gap: the CPU f32 evaluation
+                  re-run with the f64 run's decisions forced (same masks, same arg-max) matches f64 to ~2e-4 everywhere
+                  (measured on MI355X box: 828 of 3.07e8 ReLU decisions differ between CPU f32 and f64; free-running CPU
+                  f32 is 2.0e-2 from f64, forced 1.1e-4; the product is 2.4e-2 from f64).
+              parameters the reference leaves without gradient (BERT pooler, I2Iattention) have grad None;
+              key biases have an analytically zero gradient (softmax shift invariance) and are checked absolutely.
 The bf16 (throughput) mode is then held against the same CPU values with its own, looser, stated bounds.
 """
+import contextlib
 import json
 import os
 
@@ -27,8 +38,98 @@ from oracle.procedural import load_procedural, synthetic_batch  # noqa: E402
 DEV = "cuda"
 BERT_BASE = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
                  max_position_embeddings=512, type_vocab_size=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-GRAD_TOL = 2e-3        # relative L2 per parameter tensor, f32 mode
+GRAD_TOL = 2e-4        # relative L2 per parameter tensor, f32 mode, parameters with no ReLU / max-pool decision below them
+FORCED_TOL = 5e-4      # CPU f32 with the f64 run's decisions forced, against f64 (measured 1.1e-4 / 2.2e-4; free: 2e-2)
+GAP_FACTOR = 2.0       # image tower: product-vs-f64 error allowed per tensor = GAP_FACTOR * (CPU-f32-vs-f64 error) + 1e-4
 LOGIT_TOL = 1e-4
+
+
+class Decisions:
+    """ReLU masks and max-pool arg-max indices of one forward, in call order."""
+
+    def __init__(self):
+        self.relu, self.pool = [], []
+
+
+@contextlib.contextmanager
+def decisions(store, mode):
+    """mode 'record': run normally and store every ReLU mask / max-pool index; mode 'force': ignore the signs / maxima of
+    this run and apply the stored decisions (y = x * mask, y = x[argmax])."""
+    import torch.nn.functional as F
+    orig_relu, orig_pool = F.relu, F.max_pool2d
+    pos = {"r": 0, "p": 0}
+
+    def relu(x, inplace=False):
+        if mode == "record":
+            y = orig_relu(x)
+            store.relu.append(y > 0)
+            return y
+        m = store.relu[pos["r"]]
+        pos["r"] += 1
+        return x * m.to(x.dtype)
+
+    def pool(x, kernel_size, stride=None, padding=0, dilation=1, ceil_mode=False, return_indices=False):
+        if mode == "record":
+            y, idx = orig_pool(x, kernel_size, stride, padding, dilation, ceil_mode, True)
+            store.pool.append(idx)
+            return y
+        idx = store.pool[pos["p"]]
+        pos["p"] += 1
+        return x.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+
+    F.relu, F.max_pool2d = relu, pool
+    try:
+        yield
+    finally:
+        F.relu, F.max_pool2d = orig_relu, orig_pool
+
+
+def _flip_fraction(a, b):
+    flips = sum(int((x != y).sum()) for x, y in zip(a.relu, b.relu))
+    flips_pool = sum(int((x != y).sum()) for x, y in zip(a.pool, b.pool))
+    total = sum(x.numel() for x in a.relu)
+    return flips, flips_pool, total
+
+
+def _grads(model):
+    return {k: p.grad.detach().double().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+
+def _relerr(a, b):
+    return (a.double().cpu() - b).norm().item() / max(b.norm().item(), 1e-30)
+
+
+def _check_against_f64(what, prod, cpu32, forced32, g64, zero_grad_keys, decision_prefix):
+    """prod / cpu32 / forced32 / g64: name -> gradient (product f32 mode, CPU f32, CPU f32 with f64 decisions, CPU f64)"""
+    rows = []
+    scale_all = max(g.abs().max().item() for g in g64.values())
+    for k, ref in g64.items():
+        if any(k.endswith(z) for z in zero_grad_keys):        # analytically zero: compare absolutely
+            for name, g in (("product", prod[k]), ("cpu f32", cpu32[k])):
+                assert g.double().cpu().abs().max().item() <= 1e-4 * scale_all, f"{what}: {k} ({name}) should be ~0"
+            continue
+        e_prod, e_cpu, e_forced = _relerr(prod[k], ref), _relerr(cpu32[k], ref), _relerr(forced32[k], ref)
+        rows.append((e_prod, e_cpu, e_forced, k))
+    rows.sort(reverse=True)
+    dump = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(dump):
+        with open(os.path.join(dump, "fullsize_grads_" + what.replace(" ", "_") + ".txt"), "w") as f:
+            f.write("# product-vs-f64  cpu32-vs-f64  cpu32(forced f64 decisions)-vs-f64  |g64|  numel  name\n")
+            for e_prod, e_cpu, e_forced, k in rows:
+                f.write(f"{e_prod:.3e} {e_cpu:.3e} {e_forced:.3e} {g64[k].norm().item():.3e} {g64[k].numel()} {k}\n")
+    for e_prod, e_cpu, e_forced, k in rows[:5]:
+        print(f"{what}: {k}: product-vs-f64 {e_prod:.2e}, cpu32-vs-f64 {e_cpu:.2e}, cpu32 forced {e_forced:.2e}")
+    worst_forced = max(r[2] for r in rows)
+    print(f"{what}: CPU f32 with the f64 run's ReLU / max-pool decisions forced: worst gradient error {worst_forced:.2e}")
+    assert worst_forced <= FORCED_TOL, f"{what}: decision flips do not explain the f32-vs-f64 gap ({worst_forced:.2e})"
+    bad = []
+    for e_prod, e_cpu, e_forced, k in rows:
+        # image tower: ~3500 flipped decisions on either side (statistically alike); elsewhere flips are rare single events
+        # (only the head's 8192 ReLU decisions lie above the text tower / fusion) and the flat bound applies
+        limit = GAP_FACTOR * e_cpu + GRAD_TOL if k.startswith(decision_prefix) else max(GRAD_TOL, GAP_FACTOR * e_cpu)
+        if e_prod > limit:
+            bad.append((k, e_prod, e_cpu))
+    assert not bad, f"{what}: {len(bad)} gradients beyond their bound: {bad[:8]}"
 
 
 def _bert_dir(tmp_path):
@@ -98,9 +199,27 @@ def test_c2_full_size_f32_matches_cpu_oracle(tmp_path):
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     net, oracle = _c2_models(tmp_path, 31)
     images, ids, mask, labels = synthetic_batch(32, 224, 128, 30522, 7, seed=41, min_len=16)
-    ref_logits = oracle.classifier(oracle.forward_features(images, ids, mask))
-    ref_loss = torch.nn.functional.cross_entropy(ref_logits, labels, label_smoothing=0.02)
-    ref_loss.backward()
+
+    def cpu_run(model, dtype, store=None, mode=None):
+        model.zero_grad(set_to_none=True)
+        ctx = decisions(store, mode) if store is not None else contextlib.nullcontext()
+        with ctx:
+            lg = model.classifier(model.forward_features(images.to(dtype), ids, mask))
+            ls = torch.nn.functional.cross_entropy(lg, labels, label_smoothing=0.02)
+            ls.backward()
+        return lg.detach(), ls.detach(), _grads(model)
+
+    d32, d64 = Decisions(), Decisions()
+    ref_logits, ref_loss, g32 = cpu_run(oracle, torch.float32, d32, "record")       # the reference-style CPU f32 path
+    _, _, g32_forced = None, None, None
+    oracle.double()
+    _, _, g64 = cpu_run(oracle, torch.float64, d64, "record")
+    oracle.float()
+    _, _, g32_forced = cpu_run(oracle, torch.float32, d64, "force")
+    flips, flips_pool, total = _flip_fraction(d32, d64)
+    print(f"C2: {flips} of {total} ReLU decisions ({flips / total:.2e}) and {flips_pool} max-pool arg-maxima differ between "
+          f"the CPU f32 and f64 forwards")
+    del d32, d64
     g_im, g_ids, g_mask, g_lab = (t.to(DEV) for t in (images, ids, mask, labels))
 
     hamspine.set_compute_dtype("f32")
@@ -112,7 +231,11 @@ def test_c2_full_size_f32_matches_cpu_oracle(tmp_path):
     _logits_ok(logits, ref_logits, "C2 f32 logits", LOGIT_TOL)
     assert torch.equal(logits.argmax(1).cpu(), ref_logits.argmax(1)), "argmax class indices must be bit-exact"
     assert abs(loss.item() - ref_loss.item()) <= 1e-4 * abs(ref_loss.item()), (loss.item(), ref_loss.item())
-    _compare_grads(net, oracle, GRAD_TOL, "C2 f32")
+    pgr = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    assert sorted(pgr) == sorted(g64), set(pgr) ^ set(g64)
+    _check_against_f64("C2 f32", pgr, g32, g32_forced, g64, ("key.bias",), "image_encoder.model.")
+    for k, g in g32.items():                                    # _compare_grads below reads the oracle's .grad
+        dict(oracle.named_parameters())[k].grad = g.float()
 
     # throughput mode (what bench.py times) against the same CPU values
     hamspine.set_compute_dtype("bf16")
@@ -140,9 +263,25 @@ def test_c3_full_size_f32_matches_cpu_oracle(tmp_path):
     net = net.to(DEV).train()
     images, ids, mask, labels = synthetic_batch(32, 224, 128, 30522, 6, seed=43, min_len=16)
     batch = {"input_ids": ids, "attention_mask": mask, "transformed_image": images}
-    ref = oracle(batch)
-    ref_loss = oracle.cal_loss(ref, labels)
-    ref_loss.backward()
+
+    def cpu_run(dtype, store, mode):
+        oracle.zero_grad(set_to_none=True)
+        with decisions(store, mode):
+            o = oracle({"input_ids": ids, "attention_mask": mask, "transformed_image": images.to(dtype)})
+            ls = oracle.cal_loss(o, labels)
+            ls.backward()
+        return {k: v.detach() for k, v in o.items()}, ls.detach(), _grads(oracle)
+
+    d32, d64 = Decisions(), Decisions()
+    ref, ref_loss, g32 = cpu_run(torch.float32, d32, "record")
+    oracle.double()
+    _, _, g64 = cpu_run(torch.float64, d64, "record")
+    oracle.float()
+    _, _, g32_forced = cpu_run(torch.float32, d64, "force")
+    flips, flips_pool, total = _flip_fraction(d32, d64)
+    print(f"C3: {flips} of {total} ReLU decisions ({flips / total:.2e}) and {flips_pool} max-pool arg-maxima differ between "
+          f"the CPU f32 and f64 forwards")
+    del d32, d64
 
     hamspine.set_compute_dtype("f32")
     out = net({k: v.to(DEV) for k, v in batch.items()})
@@ -153,6 +292,10 @@ def test_c3_full_size_f32_matches_cpu_oracle(tmp_path):
         _logits_ok(out[k], ref[k], f"C3 f32 logits[{k}]", LOGIT_TOL)
         assert torch.equal(out[k].argmax(1).cpu(), ref[k].argmax(1)), f"argmax of {k} must be bit-exact"
     assert abs(loss.item() - ref_loss.item()) <= 1e-4 * abs(ref_loss.item()), (loss.item(), ref_loss.item())
-    _, nograd = _compare_grads(net, oracle, GRAD_TOL, "C3 f32")
+    pgr = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    assert sorted(pgr) == sorted(g64), set(pgr) ^ set(g64)
+    _check_against_f64("C3 f32", pgr, g32, g32_forced, g64, ("key.bias",), "image_encoder.")
+    nograd = sorted(k for k, p in net.named_parameters() if p.grad is None)
+    assert nograd == sorted(k for k, p in oracle.named_parameters() if k not in g64)
     # DDP(find_unused_parameters=True) semantics (reference mibf_net/train_resnet.py:134): never-used parameters stay None
     assert any(k.startswith("I2Iattention") for k in nograd) and any("pooler" in k for k in nograd)
