@@ -248,6 +248,10 @@ hs_status hs_unpack_stem_wgrad(const float* g, float* dw, int32_t K, int32_t R, 
 /* one launch per HS_CAST_MAX tensors: dst[i] (bf16) = src[i] (f32). */
 hs_status hs_cast_f32_to_bf16_multi(int32_t count, const float* const* src, void* const* dst, const int64_t* n,
                                     void* stream);
+/* dst[c][r] = src[r][c] for a bf16 matrix of R rows x C columns (leading dimensions in elements; R, C, ld % 8 == 0).
+   Used by the BertLayer backward to turn its weight gradients (dY^T X, reduction over the row index of both operands)
+   into K-contiguous GEMMs; replaces nothing in the reference (torch.nn.Linear's backward is one cuBLAS call there). */
+hs_status hs_transpose_bf16(const void* src, void* dst, int32_t R, int32_t C, int64_t ld_src, int64_t ld_dst, void* stream);
 /* out = a*x + b*y (y may be NULL); dtypes are HS_F32/HS_BF16 for inputs (shared) and output. */
 hs_status hs_axpby(int32_t in_dtype, int32_t out_dtype, const void* x, const void* y, void* out, int64_t n, float a,
                    float b, void* stream);
@@ -462,6 +466,9 @@ hs_status hs_attention_bwd(const hs_attn_desc* d, const void* q, const void* k, 
 /* weight-gradient side stream inside the composites below: 1 on (default; env HAMSPINE_OVERLAP=0 turns it off),
    0 off = every kernel of a composite runs on the caller's stream (used to time kernels in isolation). */
 void hs_set_overlap(int32_t on);
+/* BertLayer backward (bf16): weight gradients as K-contiguous GEMMs on transposed copies of dY and X (1, default) or straight
+   from the row-major operands (0); measurement / A-B testing switch. */
+void hs_set_wgrad_nt(int32_t on);
 
 /* conv + BatchNorm pair of a residual block. `w` is the f32 filter stored KRSC (channels_last). */
 typedef struct hs_conv_bn {
@@ -551,6 +558,71 @@ hs_status hs_bert_layer_fwd(const hs_bert_layer_desc* d, const void* x, void* y,
                             void* ws, int64_t ws_bytes, void* stream);
 hs_status hs_bert_layer_bwd(const hs_bert_layer_desc* d, const void* x, const void* dy, void* dx, void* saved,
                             int64_t saved_bytes, void* ws, int64_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Whole-tower executors: one call runs a complete tower forward or backward (the stem and every residual block /
+   the embeddings and every BertLayer), with the same kernels and per-composite layout code as the per-block entry
+   points above.  They exist for the host side: the unchanged reference loop calls `model(...)` once per step
+   (scripts/train.py:373-385, mibf_net/train_resnet.py:30-32), so the product can hand a whole tower to ONE C call
+   instead of ~70 (descriptors are built once per module and reused; nothing is re-planned or re-allocated per block).
+   Replaces torchvision ResNet.forward up to layer4 (reference encoder.py:88-100, mibf_net/model_resnet.py:15) and
+   transformers BertModel.forward (encoder.py:130-134, mibf_net/bert.py:11-13).                                       */
+/* ------------------------------------------------------------------------------------------- */
+/* sizeof of ABI struct number `which` as the library was compiled: 0 hs_conv_geom, 1 hs_gemm_params, 2 hs_bn_params,
+   3 hs_bn_bwd_params, 4 hs_attn_desc, 5 hs_conv_bn, 6 hs_resblock_desc, 7 hs_stem_desc, 8 hs_linear, 9 hs_norm,
+   10 hs_bert_layer_desc, 11 hs_resnet_desc, 12 hs_resnet_plan, 13 hs_bert_desc; -1 for an unknown number.  A binding
+   (the ctypes mirror in hamspine/_lib.py, a reference-side stub) checks its own declarations against it. */
+int64_t hs_abi_sizeof(int32_t which);
+
+#define HS_RESNET_MAX_BLOCKS 24
+#define HS_RESNET_MAX_TAPS 4
+typedef struct hs_resnet_desc {
+    hs_stem_desc stem;
+    int32_t n_blocks;
+    hs_resblock_desc blocks[HS_RESNET_MAX_BLOCKS];   /* layer1..layer4 flattened; block i takes block i-1's output    */
+    int32_t n_taps;                                  /* block outputs handed back (encoder.py:94-100: layer2/3/4)     */
+    int32_t tap_block[HS_RESNET_MAX_TAPS];           /* ascending block indices; the last one is n_blocks - 1          */
+} hs_resnet_desc;
+typedef struct hs_resnet_plan {
+    int64_t saved_bytes, ws_bytes;
+    int64_t tap_offset[HS_RESNET_MAX_TAPS];          /* byte offset of tap t inside `saved` (NHWC, compute dtype)      */
+    int32_t tap_C[HS_RESNET_MAX_TAPS], tap_H[HS_RESNET_MAX_TAPS], tap_W[HS_RESNET_MAX_TAPS];
+} hs_resnet_plan;
+hs_status hs_resnet_query(const hs_resnet_desc* d, hs_resnet_plan* plan);
+/* image: f32 NCHW.  The tap activations are left inside `saved` at plan.tap_offset. */
+hs_status hs_resnet_fwd(const hs_resnet_desc* d, const float* image, void* saved, int64_t saved_bytes, void* ws,
+                        int64_t ws_bytes, void* stream);
+/* dy_taps[t]: gradient of tap t (NHWC, compute dtype) or NULL; the last tap's gradient is required.  Parameter
+   gradients go to the dw / dgamma / dbeta pointers of the descriptor (NULL = frozen). */
+hs_status hs_resnet_bwd(const hs_resnet_desc* d, const void* const* dy_taps, void* saved, int64_t saved_bytes, void* ws,
+                        int64_t ws_bytes, void* stream);
+
+#define HS_BERT_MAX_LAYERS 24
+typedef struct hs_bert_desc {
+    int32_t dtype;
+    int32_t B, L, hidden, vocab, max_pos, n_types;
+    int32_t pad_id;                       /* nn.Embedding padding_idx of the word table (-1: none)                    */
+    float ln_eps, embed_dropout;          /* BertEmbeddings LayerNorm eps / dropout (0 in eval mode)                   */
+    uint64_t seed;                        /* dropout seed of this call: embeddings use it, layer i uses seed+16(i+1)   */
+    const float* word;                    /* [vocab][hidden]                                                           */
+    const float* pos;                     /* [max_pos][hidden]                                                         */
+    const float* type0;                   /* [n_types][hidden]; row 0 is used (token_type_ids = 0)                     */
+    const float* gamma;
+    const float* beta;
+    float* dword;                         /* gradient outputs, NULL = frozen                                           */
+    float* dpos;
+    float* dtype0;
+    float* dgamma;
+    float* dbeta;
+    int32_t n_layers;
+    hs_bert_layer_desc layers[HS_BERT_MAX_LAYERS];   /* attention_mask / seed fields are overridden per call           */
+} hs_bert_desc;
+/* out_offset: byte offset of last_hidden_state ([B][L][hidden], compute dtype) inside `saved`. */
+hs_status hs_bert_query(const hs_bert_desc* d, int64_t* saved_bytes, int64_t* ws_bytes, int64_t* out_offset);
+hs_status hs_bert_fwd(const hs_bert_desc* d, const int64_t* ids, const int64_t* mask, void* saved, int64_t saved_bytes,
+                      void* ws, int64_t ws_bytes, void* stream);
+hs_status hs_bert_bwd(const hs_bert_desc* d, const int64_t* ids, const int64_t* mask, const void* dy, void* saved,
+                      int64_t saved_bytes, void* ws, int64_t ws_bytes, void* stream);
 
 /* y = act(x W^T + b) with optional dropout / residual; generic Linear fwd + bwd on [M][in] rows.
    Replaces torch.nn.Linear call sites of the reference (encoder.py:80-86, modules/ *.py, model.py:195-200,

@@ -67,10 +67,17 @@ class ImageEncoder(nn.Module):
         return proj(tokens)
 
     def forward(self, x):
-        x = self.layer2(self.layer1(self.stem(x)))
-        f2 = x
-        f3 = self.layer3(f2)
-        f4 = self.layer4(f3)
+        from hamspine import tower
+        taps = None
+        if not tower._has_hooks(self):      # hooks on stem / layerN[-1] (Grad-CAM) need the per-block modules to run
+            taps = tower.resnet_taps(self.model, x, ("layer2", "layer3", "layer4") if self.multi_scale else ("layer4",))
+        if taps is not None:
+            f2, f3, f4 = taps if self.multi_scale else (None, None, taps[0])
+        else:
+            x = self.layer2(self.layer1(self.stem(x)))
+            f2 = x
+            f3 = self.layer3(f2)
+            f4 = self.layer4(f3)
         t4 = self._flatten_and_project(f4, self.proj4)
         if not self.multi_scale:
             return t4

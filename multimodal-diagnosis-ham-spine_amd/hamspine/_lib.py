@@ -124,6 +124,29 @@ class BertLayerDesc(C.Structure):
     ]
 
 
+RESNET_MAX_BLOCKS, RESNET_MAX_TAPS, BERT_MAX_LAYERS = 24, 4, 24
+
+
+class ResnetDesc(C.Structure):
+    _fields_ = [("stem", StemDesc), ("n_blocks", i32), ("blocks", ResblockDesc * RESNET_MAX_BLOCKS), ("n_taps", i32),
+                ("tap_block", i32 * RESNET_MAX_TAPS)]
+
+
+class ResnetPlan(C.Structure):
+    _fields_ = [("saved_bytes", i64), ("ws_bytes", i64), ("tap_offset", i64 * RESNET_MAX_TAPS),
+                ("tap_C", i32 * RESNET_MAX_TAPS), ("tap_H", i32 * RESNET_MAX_TAPS), ("tap_W", i32 * RESNET_MAX_TAPS)]
+
+
+class BertDesc(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("B", i32), ("L", i32), ("hidden", i32), ("vocab", i32), ("max_pos", i32), ("n_types", i32),
+        ("pad_id", i32), ("ln_eps", f32), ("embed_dropout", f32), ("seed", u64),
+        ("word", vp), ("pos", vp), ("type0", vp), ("gamma", vp), ("beta", vp),
+        ("dword", vp), ("dpos", vp), ("dtype0", vp), ("dgamma", vp), ("dbeta", vp),
+        ("n_layers", i32), ("layers", BertLayerDesc * BERT_MAX_LAYERS),
+    ]
+
+
 _lib = None
 
 
@@ -166,6 +189,7 @@ def _declare(l):
     l.hs_unpack_stem_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     l.hs_cast_f32_to_bf16_multi.argtypes = [i32, P(vp), P(vp), P(i64), vp]
     l.hs_axpby.argtypes = [i32, i32, vp, vp, vp, i64, f32, f32, vp]
+    l.hs_transpose_bf16.argtypes = [vp, vp, i32, i32, i64, i64, vp]
     l.hs_dropout.argtypes = [i32, vp, vp, i64, f32, u64, vp]
     l.hs_relu_fwd.argtypes = [i32, vp, vp, i64, vp]
     l.hs_relu_bwd.argtypes = [i32, vp, vp, vp, i64, vp]
@@ -193,6 +217,14 @@ def _declare(l):
     l.hs_bert_layer_query.argtypes = [P(BertLayerDesc), P(i64), P(i64)]
     l.hs_bert_layer_fwd.argtypes = [P(BertLayerDesc), vp, vp, vp, i64, vp, i64, vp]
     l.hs_bert_layer_bwd.argtypes = [P(BertLayerDesc), vp, vp, vp, vp, i64, vp, i64, vp]
+    l.hs_abi_sizeof.argtypes = [i32]
+    l.hs_abi_sizeof.restype = i64
+    l.hs_resnet_query.argtypes = [P(ResnetDesc), P(ResnetPlan)]
+    l.hs_resnet_fwd.argtypes = [P(ResnetDesc), vp, vp, i64, vp, i64, vp]
+    l.hs_resnet_bwd.argtypes = [P(ResnetDesc), P(vp), vp, i64, vp, i64, vp]
+    l.hs_bert_query.argtypes = [P(BertDesc), P(i64), P(i64), P(i64)]
+    l.hs_bert_fwd.argtypes = [P(BertDesc), vp, vp, vp, i64, vp, i64, vp]
+    l.hs_bert_bwd.argtypes = [P(BertDesc), vp, vp, vp, vp, i64, vp, i64, vp]
     l.hs_linear_fwd.argtypes = [i32, vp, i64, i32, P(Linear), vp, vp, i32, i32, i32, vp, vp, i32, f32, u64, vp]
     l.hs_linear_bwd.argtypes = [i32, vp, i64, i32, P(Linear), vp, vp, i32, vp, i32, i32, i32, vp, i32, vp, vp, i64, vp]
     l.hs_linear_bwd_ws_bytes.argtypes = [i64, i32, i32, i32]
@@ -213,6 +245,8 @@ def _declare(l):
     l.hs_gradcam.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
     l.hs_stage_images_u8.argtypes = [vp, vp, i32, i32, i32, P(f32), P(f32), vp]
     l.hs_set_overlap.restype = None
+    l.hs_set_wgrad_nt.argtypes = [i32]
+    l.hs_set_wgrad_nt.restype = None
     l.hs_dwconv_ws_bytes.argtypes = [i32] * 5
     l.hs_dwconv_ws_bytes.restype = i64
     l.hs_dwconv_fwd.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp]
@@ -223,6 +257,15 @@ def _declare(l):
     l.hs_layerscale_ws_bytes.restype = i64
     l.hs_patchify_fwd.argtypes = [i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     l.hs_patchify_bwd.argtypes = [i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+
+
+ABI_STRUCTS = None
+
+
+def abi_structs():
+    """(number for hs_abi_sizeof, ctypes mirror) of every struct of the C ABI"""
+    return [(0, ConvGeom), (1, GemmParams), (2, BnParams), (3, BnBwdParams), (4, AttnDesc), (5, ConvBn), (6, ResblockDesc),
+            (7, StemDesc), (8, Linear), (9, Norm), (10, BertLayerDesc), (11, ResnetDesc), (12, ResnetPlan), (13, BertDesc)]
 
 
 def check(status, what=""):

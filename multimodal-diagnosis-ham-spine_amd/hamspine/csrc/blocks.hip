@@ -394,6 +394,46 @@ static int linear_wgrad_run(Run& r, const void* x, long long M, int ldx, const h
     }
     return HS_OK;
 }
+// The same gradients from TRANSPOSED operands (bf16): dyT [out][M] and xT [in][M] are both K-contiguous along the token
+// dimension, so dW = dyT . xT^T runs on the ds_read_b128 operand path (measured 1.5-1.7x the [k][row] "tn" form on
+// BERT-base shapes, tools/gemm_sweep.py).  The bias gradient is the row sums of dyT (one extra MFMA per fragment).
+static int g_wgrad_nt = -1;                  // -1: HAMSPINE_WGRAD_NT from the environment (default on); hs_set_wgrad_nt overrides
+static bool wgrad_nt_enabled() {             // off: weight gradients from the row-major operands ("tn")
+    if (g_wgrad_nt < 0) {
+        const char* e = getenv("HAMSPINE_WGRAD_NT");
+        g_wgrad_nt = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_wgrad_nt == 1;
+}
+static int transpose_run(Run& r, const void* src, void* dst, long long R, int Cc, int ld_src) {
+    CALL(r, hs_transpose_bf16(src, dst, (int)R, Cc, ld_src, R, r.s));
+    return HS_OK;
+}
+// seg: 0 = plain; 3 = fused Q/K/V (lin = the q layer; D_seg / rowsum_seg = k, v)
+static int linear_wgrad_nt_run(Run& r, const void* xT, const void* dyT, long long M, int in_f, int out_f, float* dw, float* db,
+                               int seg_rows, float* const* dw_seg, float* const* db_seg) {
+    hs_gemm_params p = gemm_defaults(r.dt);
+    p.a_kind = HS_A_KC; p.b_kind = HS_B_KC;
+    p.M = out_f; p.N = in_f; p.K = (int)M;
+    p.A = dyT; p.B = xT;
+    p.a_elems = (long long)out_f * M;
+    p.b_elems = (long long)in_f * M;
+    p.lda = (int)M; p.ldb = (int)M;
+    p.D = dw; p.ldd = in_f; p.out_dtype = HS_F32;
+    if (seg_rows > 0) {
+        p.seg_rows = seg_rows;
+        p.D_seg[0] = dw_seg[0];
+        p.D_seg[1] = dw_seg[1];
+    }
+    if (db && hs_gemm_suggest_split(out_f, in_f, (int)M, r.dt) <= 1 && fused_bias_grad_enabled()) {
+        p.rowsum_a = db;
+        if (seg_rows > 0) {
+            p.rowsum_seg[0] = db_seg[0];
+            p.rowsum_seg[1] = db_seg[1];
+        }
+    }
+    return gemm_splitk(r, p);
+}
 // dx = dy W (* multiplier) (+ residual)
 static int linear_dgrad_run(Run& r, const hs_linear& lin, const void* w_c, const void* dy, long long M, int ldy, void* dx,
                             int lddx, int dx_dtype, int mul_mode, const void* mul_src, int ldm, const void* residual) {
@@ -1031,9 +1071,28 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
                                  d.ln2.dbeta ? d.ln2.dbeta : (scratch ? scratch + Hd : nullptr), ln_ws, ln_ws_bytes, M, Hd, r.s));
         if (d.hidden_dropout > 0.f) CALL(r, hs_dropout(r.dt, dh2, dd2, M * Hd, d.hidden_dropout, d.seed * 8 + 3, r.s));
     }
-    HS_PROPAGATE(on_side(r, [&]() { return linear_wgrad_run(r, L.g, M, I, out_l_w, g2, Hd); }));
+    // bf16: weight gradients from transposed operands (see linear_wgrad_nt_run); tbuf holds the two transposes of one layer
+    const bool nt = r.dt == HS_BF16 && wgrad_nt_enabled() && M % 8 == 0 && Hd % 8 == 0 && I % 8 == 0;
+    char* tA = nt ? (char*)r.ws.alloc(M * (long long)std::max(3 * Hd, I) * 2) : nullptr;   // dY^T
+    char* tB = nt ? (char*)r.ws.alloc(M * (long long)std::max(Hd, I) * 2) : nullptr;       // X^T
+    // bias gradient of a layer whose weight gradient is split (no fused row sums): column sums of the row-major dy
+    auto bias_by_colsum = [&](const hs_linear& lin, const void* dy_rm, int ldy) -> int {
+        hs_linear only_b = lin;
+        only_b.dw = nullptr;
+        return linear_wgrad_run(r, nullptr, M, 0, only_b, dy_rm, ldy);
+    };
+    auto wgrad = [&](const void* x_rm, int in_f, const hs_linear& lin, const void* dy_rm, int ldy) -> int {
+        if (!nt || !lin.dw) return linear_wgrad_run(r, x_rm, M, in_f, lin, dy_rm, ldy);
+        HS_PROPAGATE(transpose_run(r, dy_rm, tA, M, lin.out_f, ldy));
+        HS_PROPAGATE(transpose_run(r, x_rm, tB, M, in_f, in_f));
+        const bool fused_b = lin.db && hs_gemm_suggest_split(lin.out_f, in_f, (int)M, r.dt) <= 1 && fused_bias_grad_enabled();
+        HS_PROPAGATE(linear_wgrad_nt_run(r, tB, tA, M, in_f, lin.out_f, lin.dw, lin.db, 0, nullptr, nullptr));
+        if (lin.db && !fused_b) HS_PROPAGATE(bias_by_colsum(lin, dy_rm, ldy));
+        return HS_OK;
+    };
+    HS_PROPAGATE(on_side(r, [&]() { return wgrad(L.g, I, out_l_w, g2, Hd); }));
     HS_PROPAGATE(linear_dgrad_run(r, d.out_l, L.wo, g2, M, Hd, du, I, r.dt, HS_MUL_GELU_GRAD, L.u, I, nullptr));
-    HS_PROPAGATE(on_side(r, [&]() { return linear_wgrad_run(r, L.x1, M, Hd, d.inter_l, du, I); }));
+    HS_PROPAGATE(on_side(r, [&]() { return wgrad(L.x1, Hd, d.inter_l, du, I); }));
     // dx1 = du Wi + dh2 (residual into x1)
     HS_PROPAGATE(linear_dgrad_run(r, d.inter_l, L.wi, du, M, I, dx1, Hd, r.dt, HS_MUL_NONE, nullptr, 0, dh2));
     // ---- attention output LN + dense ----
@@ -1050,7 +1109,7 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
                                  d.ln1.dbeta ? d.ln1.dbeta : (scratch ? scratch + Hd : nullptr), ln_ws, ln_ws_bytes, M, Hd, r.s));
         if (d.hidden_dropout > 0.f) CALL(r, hs_dropout(r.dt, dh1, dd1, M * Hd, d.hidden_dropout, d.seed * 8 + 2, r.s));
     }
-    HS_PROPAGATE(on_side(r, [&]() { return linear_wgrad_run(r, L.ctx, M, Hd, ao_w, g1, Hd); }));
+    HS_PROPAGATE(on_side(r, [&]() { return wgrad(L.ctx, Hd, ao_w, g1, Hd); }));
     HS_PROPAGATE(linear_dgrad_run(r, d.ao, L.wao, g1, M, Hd, dctx, Hd, r.dt, HS_MUL_NONE, nullptr, 0, nullptr));
     // ---- attention core ----
     const char* qkv = (const char*)L.qkv;
@@ -1061,6 +1120,19 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
     HS_PROPAGATE(on_side(r, [&]() -> int {
         // one GEMM for the three weight gradients: [dWq; dWk; dWv] = dqkv^T x, rows routed to the three tensors
         const bool fused = d.q.dw && d.k.dw && d.v.dw;
+        if (fused && nt) {
+            HS_PROPAGATE(transpose_run(r, dqkv, tA, M, 3 * Hd, 3 * Hd));
+            HS_PROPAGATE(transpose_run(r, x, tB, M, Hd, Hd));
+            const bool bias_too = d.q.db && d.k.db && d.v.db && hs_gemm_suggest_split(3 * Hd, Hd, (int)M, r.dt) <= 1 &&
+                                  fused_bias_grad_enabled();
+            float* dws[2] = {d.k.dw, d.v.dw};
+            float* dbs[2] = {d.k.db, d.v.db};
+            HS_PROPAGATE(linear_wgrad_nt_run(r, tB, tA, M, Hd, 3 * Hd, d.q.dw, bias_too ? d.q.db : nullptr, Hd, dws, dbs));
+            if (bias_too) return HS_OK;
+            const hs_linear* lins[3] = {&d.q, &d.k, &d.v};
+            for (int i = 0; i < 3; ++i) HS_PROPAGATE(bias_by_colsum(*lins[i], dq ? dq + (long long)i * Hd * es : nullptr, 3 * Hd));
+            return HS_OK;
+        }
         if (fused) {
             hs_gemm_params p = gemm_defaults(r.dt);
             p.a_kind = HS_A_RC; p.b_kind = HS_B_RC;
@@ -1099,6 +1171,211 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
     }
     HS_PROPAGATE(side_join(r));
     RUN_CHECK_ARENAS(r, "bert_layer_bwd");
+    return HS_OK;
+}
+
+
+// ============================================================================================
+// whole-tower executors: ONE call runs the stem and every residual block (or the embeddings and every BertLayer) of a
+// tower, forward or backward.  Same kernels and the same per-composite layout code as the per-block entry points above;
+// what goes away is the host cost between them (a C2 step made ~70 Python -> C calls with ~3 layout passes, a descriptor
+// rebuild and several tensor allocations each: 11 ms of host time for 12.6 ms of GPU time).
+// Saved arena of a tower = for every composite, in forward order: [its output activation][its own saved layout].
+// ============================================================================================
+static long long out_bytes_of(const hs_resblock_desc& d, int dt, int* Cout, int* Ho, int* Wo) {
+    int H = d.H, W = d.W;
+    for (int i = 0; i < d.n_main; ++i) {
+        const hs_conv_bn& c = d.main[i];
+        H = (H + 2 * c.pad - c.R) / c.stride + 1;
+        W = (W + 2 * c.pad - c.R) / c.stride + 1;
+    }
+    const int C = d.main[d.n_main - 1].Cout;
+    if (Cout) *Cout = C;
+    if (Ho) *Ho = H;
+    if (Wo) *Wo = W;
+    return (long long)d.N * H * W * C * esize(dt);
+}
+struct ResnetLayout {
+    long long y_off[HS_RESNET_MAX_BLOCKS + 1];       // offset of the output of the stem (0) / of block i (i + 1) in `saved`
+    long long lay_off[HS_RESNET_MAX_BLOCKS + 1];     // offset at which that composite's own layout starts
+    long long y_bytes[HS_RESNET_MAX_BLOCKS + 1];
+    long long max_act = 0;
+};
+static int resnet_check(const hs_resnet_desc& d) {
+    HS_REQUIRE(d.n_blocks >= 1 && d.n_blocks <= HS_RESNET_MAX_BLOCKS, "resnet: n_blocks %d out of range", d.n_blocks);
+    HS_REQUIRE(d.n_taps >= 1 && d.n_taps <= HS_RESNET_MAX_TAPS, "resnet: n_taps %d out of range", d.n_taps);
+    for (int t = 0; t < d.n_taps; ++t)
+        HS_REQUIRE(d.tap_block[t] >= 0 && d.tap_block[t] < d.n_blocks && (t == 0 || d.tap_block[t] > d.tap_block[t - 1]),
+                   "resnet: tap blocks must be ascending block indices");
+    HS_REQUIRE(d.tap_block[d.n_taps - 1] == d.n_blocks - 1, "resnet: the last tap must be the last block");
+    for (int i = 0; i < d.n_blocks; ++i)
+        HS_REQUIRE(d.blocks[i].dtype == d.stem.dtype && d.blocks[i].N == d.stem.N, "resnet: block %d dtype / batch mismatch", i);
+    return HS_OK;
+}
+// forward pass over the tower; in plan mode it only lays the arenas out (and fills `lo`)
+static int resnet_fwd_run(Run& r, const hs_resnet_desc& d, const float* image, ResnetLayout& lo) {
+    const int dt = d.stem.dtype;
+    const int es = esize(dt);
+    const int P = (d.stem.H + 6 - 7) / 2 + 1, Q = (d.stem.W + 6 - 7) / 2 + 1;
+    const int P2 = (P + 2 - 3) / 2 + 1, Q2 = (Q + 2 - 3) / 2 + 1;
+    lo.y_off[0] = r.saved.mark();
+    lo.y_bytes[0] = (long long)d.stem.N * P2 * Q2 * d.stem.cb.Cout * es;
+    lo.max_act = lo.y_bytes[0];
+    char* x = (char*)r.saved.alloc(lo.y_bytes[0]);
+    lo.lay_off[0] = r.saved.mark();
+    long long wm = r.ws.mark();
+    HS_PROPAGATE(stem_fwd_run(r, d.stem, image, x));
+    r.ws.release(wm);
+    HS_REQUIRE(d.blocks[0].H == P2 && d.blocks[0].W == Q2 && d.blocks[0].main[0].Cin == d.stem.cb.Cout,
+               "resnet: block 0 does not take the stem's output shape");
+    int C = d.stem.cb.Cout, H = P2, W = Q2;
+    for (int i = 0; i < d.n_blocks; ++i) {
+        const hs_resblock_desc& b = d.blocks[i];
+        HS_REQUIRE(b.H == H && b.W == W && b.main[0].Cin == C, "resnet: block %d input shape mismatch", i);
+        lo.y_off[i + 1] = r.saved.mark();
+        lo.y_bytes[i + 1] = out_bytes_of(b, dt, &C, &H, &W);
+        lo.max_act = std::max(lo.max_act, lo.y_bytes[i + 1]);
+        char* y = (char*)r.saved.alloc(lo.y_bytes[i + 1]);
+        lo.lay_off[i + 1] = r.saved.mark();
+        wm = r.ws.mark();
+        HS_PROPAGATE(resblock_fwd_run(r, b, x, y));
+        r.ws.release(wm);
+        x = y;
+    }
+    return HS_OK;
+}
+static int resnet_bwd_run(Run& r, const hs_resnet_desc& d, const void* const* dy_taps, const ResnetLayout& lo) {
+    const int dt = d.stem.dtype;
+    // two gradient buffers walk the chain: block i reads the gradient of its output from one and writes the gradient
+    // of its input to the other
+    char* gbuf[2] = {(char*)r.ws.alloc(lo.max_act), (char*)r.ws.alloc(lo.max_act)};
+    int cur = 0;
+    const void* dy = nullptr;
+    int tap = d.n_taps - 1;
+    for (int i = d.n_blocks - 1; i >= 0; --i) {
+        const bool is_tap = tap >= 0 && d.tap_block[tap] == i;
+        const void* ext = is_tap && dy_taps ? dy_taps[tap] : nullptr;
+        if (is_tap) --tap;
+        if (i == d.n_blocks - 1) {
+            HS_REQUIRE(r.plan || ext, "resnet_bwd: the gradient of the last block's output is missing");
+            dy = ext;
+        } else if (ext) {      // an intermediate tap (multi-scale tokens): its gradient joins the one flowing down the chain
+            CALL(r, hs_axpby(dt, dt, dy, ext, gbuf[cur], lo.y_bytes[i + 1] / esize(dt), 1.f, 1.f, r.s));
+            dy = gbuf[cur];
+        }
+        const char* x = r.saved.base ? r.saved.base + lo.y_off[i] : nullptr;
+        const char* y = r.saved.base ? r.saved.base + lo.y_off[i + 1] : nullptr;
+        char* dx = gbuf[cur ^ 1];
+        r.saved.off = lo.lay_off[i + 1];
+        const long long wm = r.ws.mark();
+        HS_PROPAGATE(resblock_bwd_run(r, d.blocks[i], x, y, dy, dx));
+        r.ws.release(wm);
+        dy = dx;
+        cur ^= 1;
+    }
+    const hs_conv_bn& cb = d.stem.cb;
+    if (cb.dw || cb.dgamma || cb.dbeta) {
+        r.saved.off = lo.lay_off[0];
+        const long long wm = r.ws.mark();
+        HS_PROPAGATE(stem_bwd_run(r, d.stem, r.saved.base ? r.saved.base + lo.y_off[0] : nullptr, dy));
+        r.ws.release(wm);
+    }
+    return HS_OK;
+}
+
+// ---- BERT ----------------------------------------------------------------------------------
+struct BertTowerLayout {
+    long long ssum_off, stats_off;
+    long long y_off[HS_BERT_MAX_LAYERS + 1], lay_off[HS_BERT_MAX_LAYERS + 1];
+    long long act_bytes;
+};
+static int bert_check(const hs_bert_desc& d) {
+    HS_REQUIRE(d.n_layers >= 0 && d.n_layers <= HS_BERT_MAX_LAYERS, "bert: n_layers %d out of range", d.n_layers);
+    HS_REQUIRE(d.B > 0 && d.L > 0 && d.hidden > 0 && d.vocab > 0, "bert: bad dims");
+    HS_REQUIRE(d.word && d.pos && d.type0 && d.gamma && d.beta, "bert: null embedding parameter");
+    for (int i = 0; i < d.n_layers; ++i)
+        HS_REQUIRE(d.layers[i].dtype == d.dtype && d.layers[i].B == d.B && d.layers[i].L == d.L && d.layers[i].hidden == d.hidden,
+                   "bert: layer %d shape mismatch", i);
+    return HS_OK;
+}
+static hs_bert_layer_desc bert_layer_of(const hs_bert_desc& d, int i, const int64_t* mask) {
+    hs_bert_layer_desc l = d.layers[i];
+    l.attention_mask = mask;
+    l.seed = d.seed + 16ull * (unsigned)(i + 1);
+    return l;
+}
+static int bert_fwd_run(Run& r, const hs_bert_desc& d, const int64_t* ids, const int64_t* mask, BertTowerLayout& lo) {
+    const long long M = (long long)d.B * d.L;
+    const int es = esize(d.dtype);
+    lo.act_bytes = M * d.hidden * es;
+    lo.ssum_off = r.saved.mark();
+    void* ssum = r.saved.alloc(lo.act_bytes);
+    lo.stats_off = r.saved.mark();
+    float* stats = (float*)r.saved.alloc(2 * M * 4);
+    lo.y_off[0] = r.saved.mark();
+    char* x = (char*)r.saved.alloc(lo.act_bytes);
+    lo.lay_off[0] = r.saved.mark();
+    CALL(r, hs_bert_embed_fwd(d.dtype, ids, d.word, d.pos, d.type0, d.gamma, d.beta, ssum, x, stats, stats + M, M, d.L, d.hidden,
+                              d.vocab, d.ln_eps, d.embed_dropout, d.seed, r.s));
+    for (int i = 0; i < d.n_layers; ++i) {
+        lo.y_off[i + 1] = r.saved.mark();
+        char* y = (char*)r.saved.alloc(lo.act_bytes);
+        lo.lay_off[i + 1] = r.saved.mark();
+        const hs_bert_layer_desc l = bert_layer_of(d, i, mask);
+        const long long wm = r.ws.mark();
+        HS_PROPAGATE(bert_layer_fwd_run(r, l, x, y));
+        r.ws.release(wm);
+        x = y;
+    }
+    return HS_OK;
+}
+static int bert_bwd_run(Run& r, const hs_bert_desc& d, const int64_t* ids, const int64_t* mask, const void* dy_in,
+                        const BertTowerLayout& lo) {
+    const long long M = (long long)d.B * d.L;
+    const int Hd = d.hidden;
+    char* gbuf[2] = {(char*)r.ws.alloc(lo.act_bytes), (char*)r.ws.alloc(lo.act_bytes)};
+    int cur = 0;
+    const void* dy = dy_in;
+    char* base = r.saved.base;
+    for (int i = d.n_layers - 1; i >= 0; --i) {
+        const hs_bert_layer_desc l = bert_layer_of(d, i, mask);
+        char* dx = gbuf[cur];
+        r.saved.off = lo.lay_off[i + 1];
+        const long long wm = r.ws.mark();
+        HS_PROPAGATE(bert_layer_bwd_run(r, l, base ? base + lo.y_off[i] : nullptr, dy, dx));
+        r.ws.release(wm);
+        dy = dx;
+        cur ^= 1;
+    }
+    // embeddings: dropout mask, LayerNorm backward, scatter into the tables (BertEmbeddings with token_type_ids = 0)
+    const bool any = d.dword || d.dpos || d.dtype0 || d.dgamma || d.dbeta;
+    if (!any) return HS_OK;
+    const void* g = dy;
+    if (d.embed_dropout > 0.f) {
+        char* gd = gbuf[cur];
+        CALL(r, hs_dropout(d.dtype, dy, gd, M * Hd, d.embed_dropout, d.seed, r.s));
+        g = gd;
+        cur ^= 1;
+    }
+    char* dsum = gbuf[cur];
+    const long long lnb = hs_layernorm_bwd_ws_bytes(M, Hd);
+    const long long csb = hs_colsum_ws_bytes(M, Hd);
+    void* lnws = r.ws.alloc(lnb);
+    void* csws = r.ws.alloc(csb);
+    float* scratch = (float*)r.ws.alloc(2ll * Hd * 4);
+    const float* stats = base ? (const float*)(base + lo.stats_off) : nullptr;
+    CALL(r, hs_layernorm_bwd(d.dtype, g, base ? base + lo.ssum_off : nullptr, d.gamma, stats, stats ? stats + M : nullptr, dsum,
+                             d.dgamma ? d.dgamma : scratch, d.dbeta ? d.dbeta : (scratch ? scratch + Hd : nullptr), lnws, lnb, M,
+                             Hd, r.s));
+    if (!r.plan) {
+        if (d.dword) HS_CHECK_HIP(hipMemsetAsync(d.dword, 0, (size_t)d.vocab * Hd * 4, r.s));
+        if (d.dpos) HS_CHECK_HIP(hipMemsetAsync(d.dpos, 0, (size_t)d.max_pos * Hd * 4, r.s));
+    }
+    if (d.dword || d.dpos) CALL(r, hs_bert_embed_bwd(d.dtype, ids, dsum, d.dword, d.dpos, d.B, d.L, Hd, d.vocab, d.pad_id, r.s));
+    if (d.dtype0) {
+        if (!r.plan && d.n_types > 1) HS_CHECK_HIP(hipMemsetAsync(d.dtype0 + Hd, 0, (size_t)(d.n_types - 1) * Hd * 4, r.s));
+        CALL(r, hs_colsum(d.dtype, dsum, M, Hd, Hd, d.dtype0, csws, csb, 0, r.s));
+    }
     return HS_OK;
 }
 
@@ -1291,7 +1568,170 @@ int64_t hs_linear_bwd_ws_bytes(int64_t M, int32_t in_f, int32_t out_f, int32_t d
     const long long b = align_up(hs_colsum_ws_bytes(M, out_f), 256);
     return a + b + 1024;   // slabs and column-sum partials may be live together (side-stream overlap)
 }
+
+/* sizeof of the ABI structs as this library was compiled (a binding checks its mirror declarations against it) */
+int64_t hs_abi_sizeof(int32_t which) {
+    switch (which) {
+        case 0: return sizeof(hs_conv_geom);
+        case 1: return sizeof(hs_gemm_params);
+        case 2: return sizeof(hs_bn_params);
+        case 3: return sizeof(hs_bn_bwd_params);
+        case 4: return sizeof(hs_attn_desc);
+        case 5: return sizeof(hs_conv_bn);
+        case 6: return sizeof(hs_resblock_desc);
+        case 7: return sizeof(hs_stem_desc);
+        case 8: return sizeof(hs_linear);
+        case 9: return sizeof(hs_norm);
+        case 10: return sizeof(hs_bert_layer_desc);
+        case 11: return sizeof(hs_resnet_desc);
+        case 12: return sizeof(hs_resnet_plan);
+        case 13: return sizeof(hs_bert_desc);
+    }
+    return -1;
+}
+/* ---- whole-tower executors ------------------------------------------------------------------ */
+hs_status hs_resnet_query(const hs_resnet_desc* d, hs_resnet_plan* plan) {
+    HS_REQUIRE(d && plan, "resnet_query: null argument");
+    HS_PROPAGATE(resnet_check(*d));
+    Run r;
+    run_init(r, d->stem.dtype, true, nullptr, 0, nullptr, 0, nullptr);
+    ResnetLayout lo;
+    HS_PROPAGATE(resnet_fwd_run(r, *d, nullptr, lo));
+    Run b;
+    run_init(b, d->stem.dtype, true, nullptr, 0, nullptr, 0, nullptr);
+    hs_resnet_desc dd = *d;           // size the workspace for the trainable case
+    float dummy;
+    auto need = [&](hs_conv_bn& c) { if (!c.dw) c.dw = &dummy; if (!c.dgamma) c.dgamma = &dummy; if (!c.dbeta) c.dbeta = &dummy; };
+    need(dd.stem.cb);
+    for (int i = 0; i < dd.n_blocks; ++i) {
+        for (int j = 0; j < dd.blocks[i].n_main; ++j) need(dd.blocks[i].main[j]);
+        if (dd.blocks[i].has_ds) need(dd.blocks[i].ds);
+    }
+    HS_PROPAGATE(resnet_bwd_run(b, dd, nullptr, lo));
+    memset(plan, 0, sizeof(*plan));
+    plan->saved_bytes = r.saved.peak;
+    plan->ws_bytes = std::max(r.ws.peak, b.ws.peak);
+    for (int t = 0; t < d->n_taps; ++t) {
+        const int i = d->tap_block[t];
+        int C, H, W;
+        out_bytes_of(d->blocks[i], d->stem.dtype, &C, &H, &W);
+        plan->tap_offset[t] = lo.y_off[i + 1];
+        plan->tap_C[t] = C; plan->tap_H[t] = H; plan->tap_W[t] = W;
+    }
+    return HS_OK;
+}
+hs_status hs_resnet_fwd(const hs_resnet_desc* d, const float* image, void* saved, int64_t saved_bytes, void* ws,
+                        int64_t ws_bytes, void* stream) {
+    HS_REQUIRE(d && image && saved && ws, "resnet_fwd: null argument");
+    HS_PROPAGATE(resnet_check(*d));
+    ResnetLayout lo;
+    {
+        Run pl;
+        run_init(pl, d->stem.dtype, true, nullptr, 0, nullptr, 0, nullptr);
+        HS_PROPAGATE(resnet_fwd_run(pl, *d, nullptr, lo));
+        HS_REQUIRE(pl.saved.peak <= saved_bytes && pl.ws.peak <= ws_bytes,
+                   "resnet_fwd: arena too small (saved %lld needed / %lld given, ws %lld needed / %lld given)", pl.saved.peak,
+                   (long long)saved_bytes, pl.ws.peak, (long long)ws_bytes);
+    }
+    Run r;
+    run_init(r, d->stem.dtype, false, saved, saved_bytes, ws, ws_bytes, (hipStream_t)stream);
+    HS_PROPAGATE(resnet_fwd_run(r, *d, image, lo));
+    RUN_CHECK_ARENAS(r, "resnet_fwd");
+    return HS_OK;
+}
+hs_status hs_resnet_bwd(const hs_resnet_desc* d, const void* const* dy_taps, void* saved, int64_t saved_bytes, void* ws,
+                        int64_t ws_bytes, void* stream) {
+    HS_REQUIRE(d && dy_taps && saved && ws, "resnet_bwd: null argument");
+    HS_PROPAGATE(resnet_check(*d));
+    ResnetLayout lo;
+    {
+        Run pl;
+        run_init(pl, d->stem.dtype, true, nullptr, 0, nullptr, 0, nullptr);
+        HS_PROPAGATE(resnet_fwd_run(pl, *d, nullptr, lo));
+        Run pb;
+        run_init(pb, d->stem.dtype, true, nullptr, 0, nullptr, 0, nullptr);
+        HS_PROPAGATE(resnet_bwd_run(pb, *d, nullptr, lo));
+        HS_REQUIRE(pl.saved.peak <= saved_bytes && pb.ws.peak <= ws_bytes,
+                   "resnet_bwd: arena too small (saved %lld needed / %lld given, ws %lld needed / %lld given)", pl.saved.peak,
+                   (long long)saved_bytes, pb.ws.peak, (long long)ws_bytes);
+    }
+    Run r;
+    run_init(r, d->stem.dtype, false, saved, saved_bytes, ws, ws_bytes, (hipStream_t)stream);
+    HS_PROPAGATE(resnet_bwd_run(r, *d, dy_taps, lo));
+    RUN_CHECK_ARENAS(r, "resnet_bwd");
+    return HS_OK;
+}
+
+hs_status hs_bert_query(const hs_bert_desc* d, int64_t* saved_bytes, int64_t* ws_bytes, int64_t* out_offset) {
+    HS_REQUIRE(d, "bert_query: null desc");
+    HS_PROPAGATE(bert_check(*d));
+    Run r;
+    run_init(r, d->dtype, true, nullptr, 0, nullptr, 0, nullptr);
+    BertTowerLayout lo;
+    HS_PROPAGATE(bert_fwd_run(r, *d, nullptr, nullptr, lo));
+    Run b;
+    run_init(b, d->dtype, true, nullptr, 0, nullptr, 0, nullptr);
+    hs_bert_desc dd = *d;
+    float dummy;
+    for (int i = 0; i < dd.n_layers; ++i) {
+        hs_linear* ls[6] = {&dd.layers[i].q, &dd.layers[i].k, &dd.layers[i].v, &dd.layers[i].ao, &dd.layers[i].inter_l, &dd.layers[i].out_l};
+        for (auto* l : ls) {
+            if (!l->dw) l->dw = &dummy;
+            if (!l->db) l->db = &dummy;
+        }
+    }
+    if (!dd.dword) dd.dword = &dummy;
+    if (!dd.dtype0) dd.dtype0 = &dummy;
+    HS_PROPAGATE(bert_bwd_run(b, dd, nullptr, nullptr, nullptr, lo));
+    if (saved_bytes) *saved_bytes = r.saved.peak;
+    if (ws_bytes) *ws_bytes = std::max(r.ws.peak, b.ws.peak);
+    if (out_offset) *out_offset = lo.y_off[d->n_layers];
+    return HS_OK;
+}
+hs_status hs_bert_fwd(const hs_bert_desc* d, const int64_t* ids, const int64_t* mask, void* saved, int64_t saved_bytes,
+                      void* ws, int64_t ws_bytes, void* stream) {
+    HS_REQUIRE(d && ids && saved && ws, "bert_fwd: null argument");
+    HS_PROPAGATE(bert_check(*d));
+    BertTowerLayout lo;
+    {
+        Run pl;
+        run_init(pl, d->dtype, true, nullptr, 0, nullptr, 0, nullptr);
+        HS_PROPAGATE(bert_fwd_run(pl, *d, nullptr, nullptr, lo));
+        HS_REQUIRE(pl.saved.peak <= saved_bytes && pl.ws.peak <= ws_bytes,
+                   "bert_fwd: arena too small (saved %lld needed / %lld given, ws %lld needed / %lld given)", pl.saved.peak,
+                   (long long)saved_bytes, pl.ws.peak, (long long)ws_bytes);
+    }
+    Run r;
+    run_init(r, d->dtype, false, saved, saved_bytes, ws, ws_bytes, (hipStream_t)stream);
+    HS_PROPAGATE(bert_fwd_run(r, *d, ids, mask, lo));
+    RUN_CHECK_ARENAS(r, "bert_fwd");
+    return HS_OK;
+}
+hs_status hs_bert_bwd(const hs_bert_desc* d, const int64_t* ids, const int64_t* mask, const void* dy, void* saved,
+                      int64_t saved_bytes, void* ws, int64_t ws_bytes, void* stream) {
+    HS_REQUIRE(d && ids && dy && saved && ws, "bert_bwd: null argument");
+    HS_PROPAGATE(bert_check(*d));
+    BertTowerLayout lo;
+    {
+        Run pl;
+        run_init(pl, d->dtype, true, nullptr, 0, nullptr, 0, nullptr);
+        HS_PROPAGATE(bert_fwd_run(pl, *d, nullptr, nullptr, lo));
+        Run pb;
+        run_init(pb, d->dtype, true, nullptr, 0, nullptr, 0, nullptr);
+        HS_PROPAGATE(bert_bwd_run(pb, *d, nullptr, nullptr, nullptr, lo));
+        HS_REQUIRE(pl.saved.peak <= saved_bytes && pb.ws.peak <= ws_bytes,
+                   "bert_bwd: arena too small (saved %lld needed / %lld given, ws %lld needed / %lld given)", pl.saved.peak,
+                   (long long)saved_bytes, pb.ws.peak, (long long)ws_bytes);
+    }
+    Run r;
+    run_init(r, d->dtype, false, saved, saved_bytes, ws, ws_bytes, (hipStream_t)stream);
+    HS_PROPAGATE(bert_bwd_run(r, *d, ids, mask, dy, lo));
+    RUN_CHECK_ARENAS(r, "bert_bwd");
+    return HS_OK;
+}
 /* weight-gradient side stream inside the composites: 1 on (default, or HAMSPINE_OVERLAP), 0 off (every kernel of a
    composite on the caller's stream, e.g. to time kernels in isolation). */
 void hs_set_overlap(int32_t on) { hs::g_overlap = on ? 1 : 0; }
+/* BertLayer weight gradients from transposed (K-contiguous) operands: 1 on (default), 0 = the row-major "tn" form. */
+void hs_set_wgrad_nt(int32_t on) { hs::g_wgrad_nt = on ? 1 : 0; }
 }

@@ -63,6 +63,25 @@ static void prof_end(hipStream_t s, ProfRec& r) {
 
 __global__ void null_kernel() {}
 
+// Arrival counters of the in-launch split-K reduction (bf16 kernel): one zeroed pool per (device, stream).  Launches on
+// one stream are ordered and the reducing workgroup re-zeroes its counter, so every launch of a stream can use the same
+// counters; launches on different streams (the two towers) run concurrently and therefore get different pools.
+static constexpr int kTicketPool = 16384;
+static unsigned* ticket_pool(hipStream_t s) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, unsigned*> pools;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = pools.find({dev, s});
+    if (it != pools.end()) return it->second;
+    unsigned* p = nullptr;
+    if (hipMalloc(&p, kTicketPool * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemsetAsync(p, 0, kTicketPool * sizeof(unsigned), s) != hipSuccess) return nullptr;   // ordered before the first use
+    pools[{dev, s}] = p;
+    return p;
+}
+
 static int g_dbg_cfg = -1, g_dbg_ablate = 0;   // measurement overrides (hs_gemm_debug)
 static unsigned long long* g_dbg_stamps = nullptr;   // hs_gemm_debug_stamps: per-workgroup clock stamps of the next launches
 
@@ -78,12 +97,26 @@ static int combo_of(int ak, int bk) {
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+static bool batch_is_one(const hs_gemm_params* p) { return p->batch <= 1; }
 // tile choice for everything but the stem (see the comment at the call site)
 static int auto_cfg(const hs_gemm_params* p, bool vec) {
     const long long z = (long long)(p->batch > 0 ? p->batch : 1) * (p->split_k > 1 ? p->split_k : 1);
     const long long t12864 = (long long)ceil_div(p->M, 128) * ceil_div(p->N, 64) * z;
     const long long t128 = (long long)ceil_div(p->M, 128) * ceil_div(p->N, 128) * z;
-    if (p->dtype == HS_BF16) return t12864 >= 1536 ? CFG_128x64 : CFG_64x64;
+    if (p->dtype == HS_BF16) {
+        // plain GEMMs of BERT-base size, cold caches (tools/gemm_sweep.py on MI355X, profiles/round2_gemm_sweep.txt):
+        //   wide outputs with a short K (QKV / FFN1 forward, FFN2 data gradient: N >= 2048, K <= 1024): 128x128, BK = 32
+        //     (36.8 vs 46.3 us on nn 4096x3072x768; 37.1 vs 40.2 us on nt);
+        //   K-contiguous operands with a long K (FFN2 forward 4096x768x3072): 128x64 once it gives >= 256 tiles (40.4 vs 48.8 us).
+        // (The QKV weight gradient 2304x768x4096 would gain 18 % as 128x64 tiles split two ways, but a split launch cannot
+        // also produce the bias gradient -- rowsum_a -- and the three column-sum passes that replace it cost more.)
+        const bool plain = (p->a_kind == HS_A_KC || p->a_kind == HS_A_RC) && (p->b_kind == HS_B_KC || p->b_kind == HS_B_RC);
+        if (plain && batch_is_one(p)) {
+            if (p->a_kind == HS_A_KC && p->split_k <= 1 && p->N >= 2048 && p->K <= 1024 && p->M >= 2048 && p->K % 32 == 0) return CFG_128x128x32;
+            if (p->a_kind == HS_A_KC && p->b_kind == HS_B_KC && p->split_k <= 1 && p->K >= 2048 && t12864 >= 256) return CFG_128x64;
+        }
+        return t12864 >= 1536 ? CFG_128x64 : CFG_64x64;
+    }
     return (vec && t128 >= 200) ? CFG_128x128 : CFG_64x64;
 }
 // rows of a colstats buffer = row tiles the bf16 kernel will use for p
@@ -156,8 +189,9 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     a.rowsum[1] = p->rowsum_seg[0];
     a.rowsum[2] = p->rowsum_seg[1];
     if (p->rowsum_a) {
-        HS_REQUIRE(p->dtype == HS_BF16 && p->a_kind == HS_A_RC && p->split_k <= 1 && batch == 1,
-                   "hs_gemm: rowsum_a needs bf16, a row-contiguous A, no split-K and no batch");
+        HS_REQUIRE(p->dtype == HS_BF16 && (p->a_kind == HS_A_RC || (p->a_kind == HS_A_KC && p->b_kind == HS_B_KC)) &&
+                       p->split_k <= 1 && batch == 1,
+                   "hs_gemm: rowsum_a needs bf16, a row-contiguous A (or K-contiguous A and B), no split-K and no batch");
         HS_REQUIRE(p->seg_rows <= 0 || (p->rowsum_seg[0] && (p->M <= 2 * p->seg_rows || p->rowsum_seg[1])),
                    "hs_gemm: rowsum_a with seg_rows needs rowsum_seg");
     }
@@ -254,6 +288,7 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     // 1-20 GFLOP, i.e. a few microseconds of MFMA time, so filling the chip evenly beats per-tile arithmetic
     // intensity: 128x128 never wins, 128x64 wins once it yields >= ~1500 tiles, otherwise 64x64.
     if (cfg < 0) cfg = auto_cfg(p, vec);
+    if (p->rowsum_a && p->a_kind == HS_A_KC && cfg != CFG_128x64 && cfg != CFG_64x64) cfg = CFG_128x64;   // instantiated tiles of the RS variant
     if (g_dbg_cfg >= 0 && g_dbg_cfg <= CFG_64x64 && cfg != CFG_STEM) cfg = g_dbg_cfg;
     if (g_dbg_cfg >= CFG_256x128 && g_dbg_cfg <= CFG_256x128x32 && bf16 && !conv) cfg = g_dbg_cfg;
     int BM = 64, BN = 64;
@@ -286,6 +321,11 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
         const int ktiles = ceil_div(p->K, kb_cfg);
         a.k_per_split = ceil_div(ktiles, split) * kb_cfg;
         a.splitk_ws = p->splitk_ws;
+        // bf16: the last-arriving slice of a tile reduces it inside the launch; f32 (parity mode) keeps the second pass
+        if (bf16 && a.tiles_m * a.tiles_n <= kTicketPool && (long long)split * p->M * p->N * 4 < 0x7fffff00ll) {
+            a.tickets = ticket_pool(stream);
+            HS_REQUIRE(a.tickets != nullptr, "hs_gemm: cannot allocate the split-K arrival counters");
+        }
     }
     if (a.colstats) HS_REQUIRE(bf16 && split == 1 && batch == 1, "hs_gemm: colstats needs bf16 operands, no split-K, no batch");
     {   // measurement aid (HAMSPINE_EPI_HIST=1): which epilogue feature sets the launches use, printed at exit
@@ -341,7 +381,7 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
         prof_end(stream, rec);
     }
     HS_PROPAGATE(st);
-    if (split > 1) {
+    if (split > 1 && !a.tickets) {
         const long long work = (long long)p->M * ((p->N + 3) / 4);
         const int blocks = (int)std::min<long long>((work + 255) / 256, 2048);
         if (bf16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, a);
@@ -413,7 +453,7 @@ hs_status hs_prof_calibrate(void* stream, int32_t n, float* avg_us) {
     *avg_us = (float)(tot / n * 1e3);
     return HS_OK;
 }
-/* Synchronises, appends one CSV line per recorded launch (cls,combo,cfg,M,N,K,batch,split,R,stride,ms) to `path`, clears. */
+/* Synchronises, appends one CSV line per recorded launch (cls,combo,cfg,M,N,K,batch,split,R,stride,ms,flops) to `path`, clears. */
 hs_status hs_prof_dump(const char* path) {
     HS_CHECK_HIP(hipDeviceSynchronize());
     std::lock_guard<std::mutex> lk(hs::g_prof_mu);
@@ -422,8 +462,8 @@ hs_status hs_prof_dump(const char* path) {
     for (auto& r : hs::g_prof) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess)
-            fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.6f\n", r.cls, r.combo, r.cfg, r.M, r.N, r.K, r.batch, r.split, r.conv_r,
-                    r.conv_stride, t);
+            fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.6f,%.0f\n", r.cls, r.combo, r.cfg, r.M, r.N, r.K, r.batch, r.split, r.conv_r,
+                    r.conv_stride, t, r.flops);
         hs::g_prof_pool.emplace_back(r.a, r.b);
     }
     hs::g_prof.clear();

@@ -15,6 +15,18 @@ namespace hs {
     }                                              \
     break;
 int launch_bf16_plain(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s) {
+    if (combo == 0 && a.rowsum[0]) {        // K-contiguous weight gradient (dY^T, X^T) that also produces the bias gradient
+        switch (cfg) {
+            case CFG_128x64:
+                return launch_with_lds(gemm_bf16_kernel<128, 64, 64, HS_A_KC, HS_B_KC, true, 2, true>, a.lds_stages * 192 * 64 * 2,
+                                       3 * 192 * 64 * 2, a, grid, s);
+            case CFG_64x64:
+                return launch_with_lds(gemm_bf16_kernel<64, 64, 64, HS_A_KC, HS_B_KC, true, 2, true>, a.lds_stages * 128 * 64 * 2,
+                                       3 * 128 * 64 * 2, a, grid, s);
+        }
+        set_error("launch_bf16_plain: rowsum_a with K-contiguous operands needs the 128x64 or 64x64 tile (cfg %d)", cfg);
+        return HS_ERR_ARG;
+    }
     switch (combo) {
         case 0: CFGS(HS_A_KC, HS_B_KC)
         case 1: CFGS(HS_A_KC, HS_B_RC)

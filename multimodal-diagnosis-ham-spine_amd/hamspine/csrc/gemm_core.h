@@ -45,6 +45,8 @@ struct GemmArgs {
     int split_k;               // >1: blockIdx.z is the split index
     int k_per_split;           // multiple of BK
     float* splitk_ws;
+    unsigned* tickets;         // split-K (bf16 kernel): one arrival counter per output tile, zero before the launch; the
+                               // workgroup that draws split_k - 1 sums the slabs and runs the epilogue, then re-zeroes it
     // epilogue
     char* D;
     int ldd;
@@ -567,11 +569,14 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& a, const unsigned e
 }
 
 // WGM: waves along M (x 2 along N): 2 -> 256 threads (the default), 4 -> 512 threads for the 256-row tile.
-template <int BM, int BN, int BK, int AK, int BKIND, bool VEC, int WGM = 2>
+// RS: the row sums of A (sum over k) are produced too (rowsum[]: the bias gradient of a weight-gradient GEMM whose A operand
+// is dY, row-contiguous or -- RS instantiations -- K-contiguous dY^T); row-contiguous A always has the code.
+template <int BM, int BN, int BK, int AK, int BKIND, bool VEC, int WGM = 2, bool RS = false>
 __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) {
     typedef bf16_t T;
     constexpr int ESZ = 2;
     constexpr bool A_RC = a_is_rc(AK), B_RC = b_is_rc(BKIND);
+    constexpr bool ROWSUM = A_RC || RS;
     constexpr int NW = 2 * WGM;
     constexpr int WM = BM / WGM, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -686,9 +691,9 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // bias gradient of a weight-gradient GEMM (A = dY stored [k][m]): the column sums of dY are one more output column,
     // dY^T . 1 -- the waves of the first tile column feed their A fragments to one extra MFMA against a fragment of ones.
-    f32x4 accb[A_RC ? FM : 1];
+    f32x4 accb[ROWSUM ? FM : 1];
     bool do_rowsum = false;
-    if constexpr (A_RC) {
+    if constexpr (ROWSUM) {
         do_rowsum = a.rowsum[0] != nullptr && tn == 0 && wn == 0;
 #pragma unroll
         for (int i = 0; i < FM; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -778,7 +783,7 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
 #pragma unroll
             for (int j = 0; j < FN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        if constexpr (A_RC) {
+        if constexpr (ROWSUM) {
             if (do_rowsum) {
                 const s16x4 o4 = {0x3f80, 0x3f80, 0x3f80, 0x3f80};      // bf16 1.0
                 const bf16x8 ones = __builtin_bit_cast(bf16x8, __builtin_shufflevector(o4, o4, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -896,7 +901,7 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
     const unsigned epi = epi_flags(a);
     const int split_k = a.split_k, argM = a.M, argN = a.N;
     float* splitk_ws = a.splitk_ws;
-    if constexpr (A_RC) {
+    if constexpr (ROWSUM) {
         if (do_rowsum && g == 0) {           // every n of the ones-operand holds the same sum: lanes 0..15 write one row each
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
@@ -908,7 +913,7 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
             }
         }
     }
-    if (split_k > 1) {
+    if (split_k > 1 && !a.tickets) {                              // slabs for the separate reduce pass
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const int m = m0 + wm * WM + i * 16 + l15;
@@ -927,13 +932,82 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
         HS_STAMP(4);
         return;
     }
+    if (split_k > 1) {
+        // In-launch split-K reduction (the separate splitk_reduce pass cost 65 launches / 0.63 ms per C2 step).
+        // Protocol (cdna_hip_programming.md, "In-launch split-K reduction" / Guideline 16, counter form):
+        //   every slice workgroup: slab stores WRITE-THROUGH (sc1: the bytes leave this XCD's L2, so no release fence)
+        //   -> every wave s_waitcnt vmcnt(0) -> workgroup barrier -> ONE lane: relaxed agent-scope ticket add;
+        //   the workgroup that draws split_k - 1 is the reducer: one agent-scope acquire (drops this CU's stale L1 lines)
+        //   -> vmcnt(0) -> barrier -> all waves read every slice's slab in slice order (fixed order: deterministic sum,
+        //   whichever slice arrived last) -> re-zero the ticket for the next launch -> the normal epilogue.
+        // Placement independent: nothing depends on which XCD / CU a slice runs on or in which order slices finish.
+        const __amdgpu_buffer_rsrc_t rsW = make_rsrc(splitk_ws, (unsigned)min((unsigned long long)split_k * argM * argN * 4ull, 0x7fffff00ull));
+        const bool vecw = (argN & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * WM + i * 16 + l15;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + 4 * g;
+                if (m < argM && n < argN) {
+                    const unsigned off = (unsigned)((((long long)z * argM + m) * argN + n) * 4);
+                    if (vecw) {
+                        const u32x4 v = {__float_as_uint(acc[i][j][0]), __float_as_uint(acc[i][j][1]),
+                                         __float_as_uint(acc[i][j][2]), __float_as_uint(acc[i][j][3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsW, off, 0, 16 /* sc1: write-through */);
+                    } else {
+                        for (int e = 0; e < 4 && n + e < argN; ++e)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][e]), rsW, off + 4 * e, 0, 16);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its own stores
+        __syncthreads();
+        unsigned* ticket = a.tickets + (tm * a.tiles_n + tn);
+        int* flag = (int*)smem;                                   // the operand ring is free by now
+        if (tid == 0) *flag = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != split_k - 1) {
+            HS_STAMP(4);
+            return;                                               // (workgroup-uniform)
+        }
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int sidx = 0; sidx < split_k; ++sidx) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * WM + i * 16 + l15;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int n = n0 + wn * WN + j * 16 + 4 * g;
+                    if (m < argM && n < argN) {
+                        const HS_GLOBAL float* w = (const HS_GLOBAL float*)splitk_ws + ((long long)sidx * argM + m) * argN + n;
+                        if (vecw) {
+                            const f32x4 x = *(const HS_GLOBAL f32x4*)w;
+                            acc[i][j] += x;
+                        } else {
+                            for (int e = 0; e < 4 && n + e < argN; ++e) acc[i][j][e] += w[e];
+                        }
+                    }
+                }
+            }
+        }
+        if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // whole tile inside the matrix and 4-wide storable: one of the feature sets the training / inference steps use gets
     // branch-free code; anything else (edge tiles, rare combinations) takes the generic body
     const bool full = !a.epi_generic && (epi & EPI_VEC) && m0 + BM <= argM && n0 + BN <= argN;
     bool done = false;
+    const int ze = split_k > 1 ? 0 : z;                       // batch index seen by the epilogue (a split-K launch has no batch)
     if (full) {
         done = true;
-#define HS_EPI_CASE(F) case (F): run_epilogue<T, (F), true, FM, FN, WM, WN>(a, epi, acc, m0, n0, wm, wn, l15, g, d_boff, z); break
+#define HS_EPI_CASE(F) case (F): run_epilogue<T, (F), true, FM, FN, WM, WN>(a, epi, acc, m0, n0, wm, wn, l15, g, d_boff, ze); break
         const bool v16 = epi & EPI_VEC16;
         const unsigned key = epi & ~EPI_VEC16;
         if (!v16 && !(key & EPI_OUT_F32)) done = false;      // bf16 rows that cannot take 16-byte stores: generic body
@@ -955,7 +1029,7 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
         }
 #undef HS_EPI_CASE
     }
-    if (!done) run_epilogue<T, -1, false, FM, FN, WM, WN>(a, epi, acc, m0, n0, wm, wn, l15, g, d_boff, z);
+    if (!done) run_epilogue<T, -1, false, FM, FN, WM, WN>(a, epi, acc, m0, n0, wm, wn, l15, g, d_boff, ze);
     HS_STAMP(4);
 }
 

@@ -163,9 +163,12 @@ class BertModel(nn.Module):
             attention_mask = attention_mask.contiguous()
             if attention_mask.dtype != torch.int64:
                 attention_mask = attention_mask.long()
-        h = self.embeddings(input_ids)
-        for layer in self.encoder.layer:
-            h = layer(h, attention_mask)
+        from .. import tower
+        h = tower.bert_hidden(self, input_ids, attention_mask)      # whole tower in one node (no hooks registered)
+        if h is None:
+            h = self.embeddings(input_ids)
+            for layer in self.encoder.layer:
+                h = layer(h, attention_mask)
         return SimpleNamespace(last_hidden_state=h, pooler_output=None)
 
     # ------------------------------------------------------------------------------------------

@@ -171,6 +171,10 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def features(self, x):
+        from .. import tower
+        taps = tower.resnet_taps(self, x, ("layer4",))      # whole tower in one node (no hooks registered)
+        if taps is not None:
+            return taps[0]
         x = stem_forward(self.conv1, self.bn1, x, self.training)
         x = self.layer1(x)
         x = self.layer2(x)

@@ -102,59 +102,70 @@ class _FusedAdamBase(torch.optim.Optimizer):
         return loss
 
     def _update(self, group, ps, grad_scale):
-        """one fused launch (per 32 tensors) for the parameters `ps` of `group`, on the current stream"""
+        """one fused launch (per 32 tensors) for the parameters `ps` of `group`, on the current stream.
+
+        Host cost matters here (a C2 step has ~400 parameter tensors; the first version spent 1.5 ms per step in this
+        function): everything that does not move between steps -- parameter / moment pointer tables, sizes, strides, the
+        per-tensor checks -- is built once per parameter set, the step counter is ONE shared 0-dim tensor per chunk
+        (state[p]["step"] of every tensor in it), and the gradient pointer table is rebuilt only when a gradient pointer
+        changed (the tower executors and hamspine.ddp hand out the same gradient memory every step)."""
         if not ps:
             return
         lib = L.lib()
-        # pointer tables of everything that does not move between steps (parameters, both moments, sizes) are built once
-        # per parameter set; only the gradient table is rebuilt (gradients are fresh tensors every step)
         key = (id(group), len(ps), id(ps[0]), id(ps[-1]))
         cache = self.__dict__.setdefault("_tables", {})
         ent = cache.get(key)
-        if ent is None or ent["ps"] != [id(p) for p in ps]:
+        if ent is None or ent["ids"] != [id(p) for p in ps]:
             rt.need_gpu(*ps)
+            by_step = {}
             for p in ps:
                 st = self.state[p]
                 if not st:
-                    st["step"] = 0
+                    st["step"] = torch.zeros((), dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 if p.dtype != torch.float32:
                     raise L.HamspineError("FusedAdam expects f32 parameters and gradients")
-            by_step = {}
-            for p in ps:
-                by_step.setdefault(int(self.state[p]["step"]), []).append(p)
-            ent = {"ps": [id(p) for p in ps], "chunks": []}
+                by_step.setdefault(int(st["step"]), []).append(p)
+            ent = {"ids": [id(p) for p in ps], "chunks": []}
             for step0, sel in by_step.items():      # tensors of a group normally share the step count
                 n = len(sel)
                 arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+                shared = torch.tensor(float(step0), dtype=torch.float32)
+                for p in sel:
+                    self.state[p]["step"] = shared                       # one counter object for the whole chunk
                 ent["chunks"].append({
                     "sel": sel, "n": n, "p": arr(sel), "m": arr([self.state[p]["exp_avg"] for p in sel]),
                     "v": arr([self.state[p]["exp_avg_sq"] for p in sel]), "cnt": (C.c_int64 * n)(*[p.numel() for p in sel]),
-                    "ptrs": [p.data_ptr() for p in sel], "strides": [p.stride() for p in sel]})
+                    "ptrs": [p.data_ptr() for p in sel], "strides": [p.stride() for p in sel], "step": shared,
+                    "step_host": int(step0), "gptrs": None, "garr": None})
             cache[key] = ent
         b1, b2 = group["betas"]
         for ch in ent["chunks"]:
             sel, n = ch["sel"], ch["n"]
-            if any(p.data_ptr() != q for p, q in zip(sel, ch["ptrs"])):     # a parameter was re-allocated (.to(), load)
+            if [p.data_ptr() for p in sel] != ch["ptrs"]:     # a parameter was re-allocated (.to(), load)
                 cache.pop(key, None)
                 return self._update(group, ps, grad_scale)
-            grads = []
-            for p, st in zip(sel, ch["strides"]):
-                g = p.grad
-                if g.dtype != torch.float32:
-                    raise L.HamspineError("FusedAdam expects f32 parameters and gradients")
-                if g.stride() != st:    # rare: a gradient produced outside our nodes in another layout
-                    g2 = torch.empty_like(p, memory_format=torch.preserve_format)
-                    g2.copy_(g)
-                    p.grad = g = g2
-                grads.append(g.data_ptr())
-            step = int(self.state[sel[0]]["step"]) + 1
-            for p in sel:
-                self.state[p]["step"] = step
+            gptrs = [p.grad.data_ptr() for p in sel]
+            if gptrs != ch["gptrs"]:
+                for p, st in zip(sel, ch["strides"]):
+                    g = p.grad
+                    if g.dtype != torch.float32:
+                        raise L.HamspineError("FusedAdam expects f32 parameters and gradients")
+                    if g.stride() != st:    # rare: a gradient produced outside our nodes in another layout
+                        g2 = torch.empty_like(p, memory_format=torch.preserve_format)
+                        g2.copy_(g)
+                        p.grad = g2
+                gptrs = [p.grad.data_ptr() for p in sel]
+                ch["gptrs"], ch["garr"] = gptrs, (C.c_void_p * n)(*gptrs)
+            if self.state[sel[0]]["step"] is not ch["step"]:   # load_state_dict replaced the counters
+                cache.pop(key, None)
+                return self._update(group, ps, grad_scale)
+            ch["step_host"] += 1
+            ch["step"].fill_(ch["step_host"])                  # 0-dim CPU tensor: no device work
             L.check(lib.hs_adam_step_multi(
-                n, ch["p"], (C.c_void_p * n)(*grads), ch["m"], ch["v"], ch["cnt"], float(group["lr"]), b1, b2, group["eps"],
-                group["weight_decay"], step, 1 if self._decoupled else 0, float(grad_scale), rt.stream()),
+                n, ch["p"], ch["garr"], ch["m"], ch["v"], ch["cnt"], float(group["lr"]), b1, b2, group["eps"],
+                group["weight_decay"], ch["step_host"], 1 if self._decoupled else 0, float(grad_scale), rt.stream()),
                 "hs_adam_step_multi")
 
 

@@ -93,15 +93,23 @@ def run_on_tower_stream(fn, *inputs):
 
 
 _grad_arena = {}
+_arena_version = [0]
 
 
 def grad_arena_register(param, view):
     """hamspine.ddp: parameter -> preallocated slot of a flat gradient bucket (same shape / strides)."""
     _grad_arena[param.data_ptr()] = view
+    _arena_version[0] += 1
 
 
 def grad_arena_clear():
     _grad_arena.clear()
+    _arena_version[0] += 1
+
+
+def arena_version():
+    """changes whenever bucket slots are registered / cleared (cached tower descriptors hold gradient pointers)"""
+    return _arena_version[0]
 
 
 def grad_buffer_like(param):

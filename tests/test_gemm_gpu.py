@@ -218,3 +218,51 @@ def test_conv_fwd_dgrad_wgrad(dtype, case):
         raw.gemm(dyg, xg, dw, K, RSC, N * P * Q, a_kind=L.A_RC, b_kind=L.B_CONV, lda=K, ldd=RSC, geom=g,
                  split_k=split)
         assert (dw.cpu().double() - wd.grad).abs().max() <= tol * N * P * Q * dy.abs().max().item() * x.abs().max().item()
+
+
+@pytest.mark.parametrize("kind,M,N,K,split", [("tn", 768, 768, 4096, 4), ("tn", 256, 64, 12800, 16), ("nt", 512, 768, 3072, 3),
+                                               ("nn", 320, 200, 2048, 2), ("tn", 104, 72, 5000, 5)])
+def test_splitk_in_launch_reduction(kind, M, N, K, split):
+    """bf16 split-K reduces inside the launch (the slice workgroup that arrives last sums the slabs in slice order and runs
+    the epilogue; no second pass): equal to the unsplit GEMM up to f32 summation order, bit-identical from launch to launch
+    (the sum order does not depend on which slice arrives last), repeatable back to back on one stream (the arrival
+    counters re-zero themselves), and on two streams at once (each stream has its own counters)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    BF = torch.bfloat16
+    if kind == "nt":
+        A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+        kw = dict(a_kind=L.A_KC, b_kind=L.B_KC, lda=K, ldb=K)
+        ref = A.to(BF).float() @ B.to(BF).float().T
+    elif kind == "nn":
+        A, B = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
+        kw = dict(a_kind=L.A_KC, b_kind=L.B_RC, lda=K, ldb=N)
+        ref = A.to(BF).float() @ B.to(BF).float()
+    else:
+        A, B = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+        kw = dict(a_kind=L.A_RC, b_kind=L.B_RC, lda=M, ldb=N)
+        ref = A.to(BF).float().T @ B.to(BF).float()
+    bias = torch.randn(N, generator=g)
+    Ad, Bd, bd = A.to(DEV).to(BF), B.to(DEV).to(BF), bias.to(DEV)
+    outs = []
+    for _ in range(3):
+        D = torch.full((M, N), float("nan"), device=DEV)
+        raw.gemm(Ad, Bd, D, M, N, K, bias=bd, split_k=split, **kw)
+        outs.append(D.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    want = ref + bias
+    err = (outs[0] - want).abs().max().item()
+    assert err <= 2e-3 * want.abs().max().item(), err
+    D1 = torch.empty((M, N), device=DEV)
+    raw.gemm(Ad, Bd, D1, M, N, K, bias=bd, **kw)
+    assert (D1.cpu() - outs[0]).abs().max().item() <= 1e-4 * want.abs().max().item()
+    # two streams at once
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    Da, Db = torch.empty((M, N), device=DEV), torch.empty((M, N), device=DEV)
+    torch.cuda.synchronize()
+    for _ in range(4):
+        with torch.cuda.stream(s1):
+            raw.gemm(Ad, Bd, Da, M, N, K, bias=bd, split_k=split, **kw)
+        with torch.cuda.stream(s2):
+            raw.gemm(Ad, Bd, Db, M, N, K, bias=bd, split_k=split, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(Da.cpu(), outs[0]) and torch.equal(Db.cpu(), outs[0])

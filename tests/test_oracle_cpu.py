@@ -241,6 +241,15 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.hs_version() >= 100
 
 
+def test_ctypes_mirrors_match_the_compiled_abi_structs():
+    import ctypes
+    import hamspine._lib as L
+    lib = L.lib()
+    for which, mirror in L.abi_structs():
+        assert lib.hs_abi_sizeof(which) == ctypes.sizeof(mirror), (which, mirror.__name__, lib.hs_abi_sizeof(which))
+    assert lib.hs_abi_sizeof(99) == -1
+
+
 def test_product_refuses_cpu_tensors():
     import hamspine
     from hamspine import functional as F

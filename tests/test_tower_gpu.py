@@ -1,0 +1,148 @@
+"""Whole-tower executors (hs_resnet_* / hs_bert_*: one C call per tower and direction) against the per-block autograd
+nodes they replace, the transposed-operand weight gradients against the row-major ones, and the bf16 transpose kernel.
+The per-block path is itself held against the reference's vectors and the CPU oracle in test_product_gpu.py."""
+import os
+
+import pytest
+import torch
+
+import golden_cases as gc
+
+pytestmark = pytest.mark.gpu
+
+import hamspine  # noqa: E402
+from hamspine import _lib as L  # noqa: E402
+from hamspine import rt  # noqa: E402
+from oracle.procedural import load_procedural  # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _restore():
+    yield
+    os.environ.pop("HAMSPINE_TOWER_EXEC", None)
+    hamspine.set_compute_dtype("bf16")
+    L.lib().hs_set_wgrad_nt(1)
+
+
+def _run_e2e(name, tmp_path, tower, mode):
+    import model as product_model
+    from hamspine import functional as F
+    os.environ["HAMSPINE_TOWER_EXEC"] = "1" if tower else "0"
+    hamspine.set_compute_dtype(mode)
+    seed, kw = gc.E2E_CASES[name]
+    d = gc.save_bert_dir(gc.TINY_BERT, str(tmp_path / f"bert{int(tower)}"))
+    m = product_model.MultimodalBaselineModel(pretrained_image=False, image_weights_path=None, text_model_name=d,
+                                              **gc.E2E_COMMON, **kw)
+    load_procedural(m, seed)
+    m = m.to(DEV).train()
+    images, ids, mask, labels, tab = [t.to(DEV) for t in gc.e2e_inputs(kw)]
+    outs = []
+    for _ in range(2):                 # two steps: the second one reuses the cached descriptors and gradient buffers
+        m.zero_grad(set_to_none=True)
+        logits = gc.e2e_forward(m, name, kw, images, ids, mask, tab)
+        loss = F.cross_entropy(logits, labels, label_smoothing=0.02)
+        loss.backward()
+        torch.cuda.synchronize()
+        outs.append((logits.detach().float().cpu(), {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters()
+                                                     if p.grad is not None}))
+    bufs = {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+    return outs, bufs
+
+
+@pytest.mark.parametrize("name", ["e2e_basic_mlp", "e2e_multiscale_residual", "e2e_gate_globallocal"])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_tower_executor_equals_per_block_nodes(name, mode, tmp_path):
+    """same kernels in the same order on the same values: logits, every gradient and the BatchNorm buffers must be
+    bit-identical between the one-call tower path and the per-block path (multi-scale taps, two tower passes per step
+    with gate / global-local, both compute dtypes), on the first step and on the second (cached) one"""
+    a, abuf = _run_e2e(name, tmp_path, True, mode)
+    b, bbuf = _run_e2e(name, tmp_path, False, mode)
+    for step in range(2):
+        assert torch.equal(a[step][0], b[step][0]), f"step {step}: logits differ by {(a[step][0] - b[step][0]).abs().max():.3e}"
+        assert a[step][1].keys() == b[step][1].keys()
+        for k in a[step][1]:
+            assert torch.equal(a[step][1][k], b[step][1][k]), f"step {step}: gradient {k} differs"
+    assert abuf.keys() == bbuf.keys()
+    for k in abuf:
+        assert torch.equal(abuf[k], bbuf[k]), f"buffer {k} differs"
+
+
+def test_tower_falls_back_when_a_hook_is_registered(tmp_path):
+    """Grad-CAM style hooks on a stage boundary (reference scripts/run_analysis.py:126-133) must still fire"""
+    import model as product_model
+    seed, kw = gc.E2E_CASES["e2e_basic_mlp"]
+    d = gc.save_bert_dir(gc.TINY_BERT, str(tmp_path / "bert"))
+    m = product_model.MultimodalBaselineModel(pretrained_image=False, image_weights_path=None, text_model_name=d,
+                                              **gc.E2E_COMMON, **kw)
+    m = load_procedural(m, seed).to(DEV).eval()
+    images, ids, mask, labels, tab = [t.to(DEV) for t in gc.e2e_inputs(kw)]
+    seen = {}
+    h = m.image_encoder.layer4[-1].register_forward_hook(lambda mod, i, out: seen.__setitem__("l4", out.shape))
+    ref = m(images, ids, mask)
+    assert seen["l4"] == (4, 512, 2, 2)
+    h.remove()
+    again = m(images, ids, mask)          # tower path now
+    assert torch.equal(ref, again)
+
+
+def test_tower_gradient_accumulation_without_zero_grad(tmp_path):
+    """two backwards without zero_grad: the second must ADD to the first (the tower's cached gradient buffer may not be
+    overwritten while a parameter still holds it)"""
+    import model as product_model
+    from hamspine import functional as F
+    hamspine.set_compute_dtype("f32")
+    seed, kw = gc.E2E_CASES["e2e_basic_mlp"]
+    d = gc.save_bert_dir(gc.TINY_BERT, str(tmp_path / "bert"))
+    m = product_model.MultimodalBaselineModel(pretrained_image=False, image_weights_path=None, text_model_name=d,
+                                              **gc.E2E_COMMON, **kw)
+    m = load_procedural(m, seed).to(DEV).train()
+    images, ids, mask, labels, tab = [t.to(DEV) for t in gc.e2e_inputs(kw)]
+
+    def bwd():
+        F.cross_entropy(m.classifier(m.forward_features(images, ids, mask)), labels).backward()
+    bwd()
+    g1 = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    bwd()                                 # accumulates (BatchNorm batch statistics do not depend on the running buffers)
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        want = 2.0 * g1[k]
+        err = (p.grad - want).abs().max().item()
+        assert err <= 1e-5 * max(want.abs().max().item(), 1e-6) + 1e-9, f"{k}: accumulated gradient off by {err:.3e}"
+
+
+@pytest.mark.parametrize("R,Cc", [(4096, 768), (256, 3072), (72, 40), (64, 64)])
+def test_transpose_bf16(R, Cc):
+    x = torch.randn(R, Cc, generator=torch.Generator().manual_seed(R + Cc)).bfloat16().to(DEV)
+    y = torch.empty(Cc, R, dtype=torch.bfloat16, device=DEV)
+    L.check(L.lib().hs_transpose_bf16(x.data_ptr(), y.data_ptr(), R, Cc, Cc, R, rt.stream()), "hs_transpose_bf16")
+    assert torch.equal(y.cpu(), x.cpu().T.contiguous())
+
+
+def test_bert_weight_gradients_transposed_operands_equal_row_major():
+    """BertLayer backward in bf16: dW from transposed (K-contiguous) copies of dY and X, with the bias gradients as row sums
+    of dY^T, against the row-major form: f32 accumulation in both, the K order inside a tile differs -> 1e-5 relative"""
+    from hamspine.nn import BertConfig, BertModel
+    hamspine.set_compute_dtype("bf16")
+    cfg = BertConfig(vocab_size=500, hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=3072,
+                     max_position_embeddings=128, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = load_procedural(BertModel(cfg), 4).to(DEV).train()
+    ids = torch.randint(1, 500, (8, 128), generator=torch.Generator().manual_seed(1)).to(DEV)
+    mask = torch.ones(8, 128, dtype=torch.long, device=DEV)
+    mask[3, 70:] = 0
+    cot = torch.randn(8, 128, 768, generator=torch.Generator().manual_seed(2)).to(DEV)
+    grads = []
+    for nt in (1, 0):
+        L.lib().hs_set_wgrad_nt(nt)
+        m.zero_grad(set_to_none=True)
+        (m(input_ids=ids, attention_mask=mask).last_hidden_state.float() * cot).sum().backward()
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters() if p.grad is not None})
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        if k.endswith("key.bias"):
+            continue                      # analytically zero gradient: rounding noise on both sides
+        err = (a - b).norm().item() / max(b.norm().item(), 1e-12)
+        assert err <= 1e-5, f"{k}: transposed-operand gradient differs from the row-major one by {err:.3e}"
