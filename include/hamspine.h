@@ -597,6 +597,13 @@ hs_status hs_resnet_fwd(const hs_resnet_desc* d, const float* image, void* saved
 hs_status hs_resnet_bwd(const hs_resnet_desc* d, const void* const* dy_taps, void* saved, int64_t saved_bytes, void* ws,
                         int64_t ws_bytes, void* stream);
 
+/* Test / analysis aid (tests/test_decisions_gpu.py): byte offsets, inside the `saved` arena of hs_resnet_fwd, of every
+   ReLU output of the tower and of the stem's max-pool arg-max, in forward order: [0] stem BN+ReLU output ([N][P][Q][C],
+   compute dtype), [1] max-pool arg-max taps (uint8 [N][P2][Q2][C], tap = 3*dh + dw inside the 3x3 window), then per block
+   its inner stage outputs (n_main - 1 of them) and its output.  Returns the number of entries (-1: bad descriptor or
+   max_entries too small). */
+int32_t hs_resnet_debug_offsets(const hs_resnet_desc* d, int64_t* out, int32_t max_entries);
+
 #define HS_BERT_MAX_LAYERS 24
 typedef struct hs_bert_desc {
     int32_t dtype;

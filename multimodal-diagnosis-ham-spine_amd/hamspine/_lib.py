@@ -221,6 +221,7 @@ def _declare(l):
     l.hs_abi_sizeof.restype = i64
     l.hs_resnet_query.argtypes = [P(ResnetDesc), P(ResnetPlan)]
     l.hs_resnet_fwd.argtypes = [P(ResnetDesc), vp, vp, i64, vp, i64, vp]
+    l.hs_resnet_debug_offsets.argtypes = [P(ResnetDesc), P(i64), i32]
     l.hs_resnet_bwd.argtypes = [P(ResnetDesc), P(vp), vp, i64, vp, i64, vp]
     l.hs_bert_query.argtypes = [P(BertDesc), P(i64), P(i64), P(i64)]
     l.hs_bert_fwd.argtypes = [P(BertDesc), vp, vp, vp, i64, vp, i64, vp]

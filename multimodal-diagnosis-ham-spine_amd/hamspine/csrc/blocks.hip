@@ -1662,6 +1662,40 @@ hs_status hs_resnet_bwd(const hs_resnet_desc* d, const void* const* dy_taps, voi
     return HS_OK;
 }
 
+/* test / analysis aid: where the post-activation buffers of the image tower live inside `saved` (every ReLU output and the
+   max-pool arg-max), in forward order: out[0] = stem BN+ReLU output [N][P][Q][C], out[1] = stem max-pool arg-max taps
+   (uint8 [N][P2][Q2][C], tap = 3*dh + dw of the 3x3 window), then per block its inner stage outputs (n_main - 1 entries)
+   followed by the block output.  Returns the number of entries written (<= max_entries), or -1. */
+int32_t hs_resnet_debug_offsets(const hs_resnet_desc* d, int64_t* out, int32_t max_entries) {
+    if (!d || !out || resnet_check(*d) != HS_OK) return -1;
+    char* const fake = (char*)(uintptr_t)0x100000;
+    Run r;
+    run_init(r, d->stem.dtype, true, nullptr, 0, nullptr, 0, nullptr);
+    ResnetLayout lo;
+    if (resnet_fwd_run(r, *d, nullptr, lo) != HS_OK) return -1;
+    int n = 0;
+    auto put = [&](long long off) { if (n < max_entries) out[n] = off; ++n; };
+    {   // stem: replay its layout at its offset with a non-null base so that the pointers carry the offsets
+        Run q;
+        run_init(q, d->stem.dtype, false, fake, 1ll << 50, fake, 1ll << 50, nullptr);
+        q.saved.off = lo.lay_off[0];
+        StemLayout L;
+        if (stem_layout(q, d->stem, L) != HS_OK) return -1;
+        put((char*)L.a - fake);
+        put((char*)L.idx - fake);
+    }
+    for (int i = 0; i < d->n_blocks; ++i) {
+        Run q;
+        run_init(q, d->stem.dtype, false, fake, 1ll << 50, fake, 1ll << 50, nullptr);
+        q.saved.off = lo.lay_off[i + 1];
+        ResLayout L;
+        if (res_layout(q, d->blocks[i], L) != HS_OK) return -1;
+        for (int j = 0; j + 1 < d->blocks[i].n_main; ++j) put((char*)L.main[j].a - fake);
+        put(lo.y_off[i + 1]);
+    }
+    return n <= max_entries ? n : -1;
+}
+
 hs_status hs_bert_query(const hs_bert_desc* d, int64_t* saved_bytes, int64_t* ws_bytes, int64_t* out_offset) {
     HS_REQUIRE(d, "bert_query: null desc");
     HS_PROPAGATE(bert_check(*d));

@@ -291,6 +291,10 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     if (p->rowsum_a && p->a_kind == HS_A_KC && cfg != CFG_128x64 && cfg != CFG_64x64) cfg = CFG_128x64;   // instantiated tiles of the RS variant
     if (g_dbg_cfg >= 0 && g_dbg_cfg <= CFG_64x64 && cfg != CFG_STEM) cfg = g_dbg_cfg;
     if (g_dbg_cfg >= CFG_256x128 && g_dbg_cfg <= CFG_256x128x32 && bf16 && !conv) cfg = g_dbg_cfg;
+    // (A deeper operand ring -- 5 / 8 slots for the long-K split weight gradients of the convolutions -- was built and
+    // measured: 1.93 vs 1.92 ms per step on the 1x1 weight gradients, 0.70 vs 0.52 ms on the 3x3 ones, where the larger LDS
+    // footprint costs a resident workgroup.  The kernel keeps the ring depth as a template parameter; 3 is what runs.)
+    const int ring = 3;
     int BM = 64, BN = 64;
     if (cfg == CFG_128x128 || cfg == CFG_128x128x32) { BM = 128; BN = 128; }
     else if (cfg == CFG_256x128 || cfg == CFG_256x128x32) { BM = 256; BN = 128; }
@@ -303,7 +307,7 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
         // 5-6 workgroups instead of 2 share a CU and hide each other's load -> MFMA -> store latency chain)
         const int ktiles_all = ceil_div(p->K, kb_cfg);
         const int kt = split > 1 ? ceil_div(ktiles_all, split) : ktiles_all;
-        a.lds_stages = std::max(1, std::min(3, kt));
+        a.lds_stages = std::max(1, std::min(ring, kt));
         // L2 grouping: an XCD runs S workgroups at a time (32 CUs x resident workgroups); the panels they touch are
         // fewest when group_m * BM == (S / group_m) * BN
         const int lds = bf16 ? a.lds_stages * (BM + BN) * kb_cfg * 2 : 2 * (BM + BN) * 32 * 4;
@@ -490,7 +494,12 @@ int32_t hs_gemm_suggest_split(int32_t M, int32_t N, int32_t K, int32_t dtype) {
     const long long tiles = (long long)hs::ceil_div(M, 64) * hs::ceil_div(N, 64);
     const int ktiles = hs::ceil_div(K, bk);
     if (tiles >= 256 || ktiles < 16) return 1;
-    long long s = (512 + tiles - 1) / tiles;   // 256/384/768 work units measured the same on C2 (16.3-16.4 ms/step)
+    static const long long units = [] {          // measurement: HAMSPINE_SPLIT_UNITS overrides the target number of workgroups
+        const char* e = getenv("HAMSPINE_SPLIT_UNITS");
+        const long long v = e ? atoll(e) : 0;
+        return v > 0 ? v : 512ll;
+    }();
+    long long s = (units + tiles - 1) / tiles;   // 256/384/768 work units measured the same on C2 with the separate reduce pass
     const long long smax = ktiles / 8 > 0 ? ktiles / 8 : 1;   // keep >= 8 k-tiles per split
     if (s > smax) s = smax;
     if (s > 64) s = 64;

@@ -571,7 +571,23 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& a, const unsigned e
 // WGM: waves along M (x 2 along N): 2 -> 256 threads (the default), 4 -> 512 threads for the 256-row tile.
 // RS: the row sums of A (sum over k) are produced too (rowsum[]: the bias gradient of a weight-gradient GEMM whose A operand
 // is dY, row-contiguous or -- RS instantiations -- K-contiguous dY^T); row-contiguous A always has the code.
-template <int BM, int BN, int BK, int AK, int BKIND, bool VEC, int WGM = 2, bool RS = false>
+// NS: slots of the LDS operand ring (3 by default).  Long-K launches that cannot fill the chip with workgroups (split-K weight
+// gradients of the convolutions: 1-2 workgroups per CU, HBM-bound streams of 64 MB and more) take a deeper ring: with NS - 1
+// tiles in flight per workgroup instead of 2, a CU keeps enough bytes in flight to cover the memory latency.
+template <int NDMA>
+__device__ __forceinline__ void wait_vm_tiles(int tiles) {       // wait until at most `tiles` of this wave's tile DMAs are in flight
+    switch (tiles) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMA) : "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NDMA) : "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * NDMA) : "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * NDMA) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * NDMA) : "memory"); break;
+    }
+}
+template <int BM, int BN, int BK, int AK, int BKIND, bool VEC, int WGM = 2, bool RS = false, int NS = 3>
 __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) {
     typedef bf16_t T;
     constexpr int ESZ = 2;
@@ -708,6 +724,7 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
     //    before the MFMAs of phase p, into the other half of a double-buffered fragment set, so the LDS latency
     //    hides under 8..16 MFMAs instead of stalling every MFMA pair.
     constexpr int NDMA = A_NI + B_NI;
+    static_assert(NS >= 3 && NS <= 8 && (NS - 1) * NDMA <= 63, "ring depth: the vmcnt field holds 6 bits");
     constexpr int KS = BK / 32;
     int ntiles = (kend - kbeg + BK - 1) / BK;
     // stride-2 dgrad with parity-major rows: when every row of this tile is in one parity class, only the filter taps
@@ -794,25 +811,24 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
     };
 
     int cur = 0;   // slot of tile t
-    // tile boundary: this wave's reads of slot `cur` are complete and its DMAs of tile t+1 have landed; after the barrier
-    // so have everyone else's, and slot `cur` takes tile t+3.
+    // tile boundary: this wave's reads of slot `cur` are complete and its DMAs of tile t+1 have landed (tiles t+2 ..
+    // t+NS-1 may still be in flight); after the barrier so have everyone else's, and slot `cur` takes tile t+NS.
     auto next_tile = [&](int t) {
-        if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_vm_tiles<NDMA>(min(NS - 1, ntiles - 1 - t) - 1);
         __builtin_amdgcn_s_barrier();
-        if (t + 3 < ntiles) stage_dma(cur, k_of(t + 3));
-        cur = cur == 2 ? 0 : cur + 1;
+        if (t + NS < ntiles) stage_dma(cur, k_of(t + NS));
+        cur = cur == NS - 1 ? 0 : cur + 1;
     };
 
     if (ntiles > 0) {
         stage_dma(0, k_of(0));
         HS_STAMP(1);
         if (a.stamps && threadIdx.x == 0) a.stamps[((long long)blockIdx.z * gridDim.x + blockIdx.x) * 6] = t_entry;
-        if (ntiles > 1) stage_dma(1, k_of(1));
-        if (ntiles > 2) stage_dma(2, k_of(2));
-        if (ntiles > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
-        else if (ntiles > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 1; q < NS; ++q)
+            if (q < ntiles) stage_dma(q, k_of(q));
+        wait_vm_tiles<NDMA>(min(NS, ntiles) - 1);
         __builtin_amdgcn_s_barrier();
         HS_STAMP(2);
         bf16x8 a0[FM], b0[FN], a1[FM], b1[FN];

@@ -23,6 +23,7 @@ from . import _lib as L
 from . import rt
 
 _CACHE_ATTR = "_hamspine_tower_cache"
+DEBUG_KEEP = None      # tests set this to a list: every ResNet tower forward appends (cache entry, saved arena)
 
 
 def _has_hooks(root):
@@ -37,8 +38,17 @@ def _has_hooks(root):
 
 
 def towers_enabled():
+    """One node per tower needs no gradient exchange DURING the tower's backward: under data parallelism (hamspine.ddp or
+    torch's DistributedDataParallel, reference mibf_net/train_resnet.py:134) the per-block nodes stay, because their
+    parameter gradients become final -- and their buckets' all-reduces start -- layer by layer while the rest of the
+    backward still runs; a one-node tower would release all of its gradients at its end."""
     import os
-    return os.environ.get("HAMSPINE_TOWER_EXEC", "1") != "0"
+    if os.environ.get("HAMSPINE_TOWER_EXEC", "1") == "0":
+        return False
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return os.environ.get("HAMSPINE_TOWER_EXEC") == "force"
+    return True
 
 
 class _GradStore:
@@ -153,11 +163,48 @@ class _ResnetEntry:
                      for t in range(len(taps))]
         self.dtype = dtype
         self.arena_version = rt.arena_version()
+        self.outstanding = self.peak = 0
 
     def valid_for(self, params):
         if self.arena_version != rt.arena_version():
             return False
         return all(p.data_ptr() == q for p, q in zip(params, self.param_ptrs))
+
+
+class _Pending:
+    """one differentiable forward of a tower whose backward has not run yet (released by the backward, or when the graph
+    is dropped without one)"""
+
+    def __init__(self, ent):
+        self.ent = ent
+        ent.outstanding += 1
+        ent.peak = max(ent.peak, ent.outstanding)
+
+    def finish(self):
+        ent, self.ent = self.ent, None
+        if ent is not None:
+            ent.outstanding = max(0, ent.outstanding - 1)
+            if ent.outstanding == 0:
+                ent.peak = 0
+
+    __del__ = finish
+
+
+def _forward_begins(ent, needs):
+    """a forward that will be backpropagated starts: count the forwards of this entry whose backward is still pending"""
+    return _Pending(ent) if any(needs) else None
+
+
+def _shared_buffer_unsafe(ent, params):
+    """may this backward write into the entry's cached gradient buffer?  Not when the tower ran more than once in the graph
+    being differentiated (gate / global-local models: reference model.py:257-281,334-337 -- autograd sums the gradients of
+    the passes AFTER all of them were produced, so each pass needs memory of its own), and not when a parameter still holds
+    the buffer from an earlier backward (accumulation without zero_grad)."""
+    if ent.store is None:
+        return ent.peak > 1            # DDP bucket slots: zero-copy is only registered for single-pass models (hamspine.ddp)
+    if ent.peak > 1:
+        return True
+    return any(p.grad is not None and p.grad.data_ptr() == ent.store.ptr(i) for i, p in enumerate(params))
 
 
 class ResNetTowerFn(Function):
@@ -188,6 +235,9 @@ class ResNetTowerFn(Function):
             outs.append(t)
         ctx.ent, ctx.saved_buf = ent, saved
         ctx.params = params
+        ctx.counted = _forward_begins(ent, needs)
+        if DEBUG_KEEP is not None:
+            DEBUG_KEEP.append((ent, saved))
         return tuple(outs)
 
     @staticmethod
@@ -207,15 +257,14 @@ class ResNetTowerFn(Function):
             ptrs[t] = dy.data_ptr()
         desc = ent.desc
         views = ent.make_views
-        if ent.store is not None and any(p.grad is not None and p.grad.data_ptr() == q for p, q in
-                                         zip(params, (ent.store.ptr(i) for i in range(len(params))))):
-            # a gradient of an earlier backward is still held in the flat buffer (accumulation without zero_grad):
-            # this backward must not overwrite it -> one-off private buffers
+        if _shared_buffer_unsafe(ent, params):      # one-off private gradient buffers for this backward
             desc, views = _resnet_desc_with_fresh_grads(ent, params, tuple(ctx.needs_input_grad[2:]), saved.device)
         ws = rt.workspace(int(ent.plan.ws_bytes), saved.device)
         L.check(L.lib().hs_resnet_bwd(C.byref(desc), ptrs, saved.data_ptr(), saved.numel(), ws.data_ptr(), ws.numel(),
                                       rt.stream()), "hs_resnet_bwd")
         ctx.saved_buf = None
+        if ctx.counted is not None:
+            ctx.counted.finish()
         return (None, None, *views())
 
 
@@ -324,6 +373,7 @@ class _BertEntry:
         self.dtype = dtype
         self.shape = (B, Lq, H)
         self.arena_version = rt.arena_version()
+        self.outstanding = self.peak = 0
 
     def valid_for(self, params):
         if self.arena_version != rt.arena_version():
@@ -362,6 +412,7 @@ class BertTowerFn(Function):
         out = saved[ent.out_off:ent.out_off + Bq * Lq2 * H * es].view(dtype).view(Bq, Lq2, H)
         ctx.ent, ctx.saved_buf, ctx.seed = ent, saved, seed
         ctx.ids, ctx.mask, ctx.params = ids, mask, params
+        ctx.counted = _forward_begins(ent, needs)
         return out
 
     @staticmethod
@@ -373,14 +424,15 @@ class BertTowerFn(Function):
         if dy.dtype != ent.dtype:
             dy = dy.to(ent.dtype)
         desc, views = ent.desc, ent.make_views
-        if ent.store is not None and any(p.grad is not None and p.grad.data_ptr() == q for p, q in
-                                         zip(params, (ent.store.ptr(i) for i in range(len(params))))):
+        if _shared_buffer_unsafe(ent, params):
             desc, views = _bert_desc_with_fresh_grads(ent, params, tuple(ctx.needs_input_grad[3:]), saved.device)
         desc.seed = ctx.seed
         ws = rt.workspace(ent.ws_bytes, saved.device)
         L.check(L.lib().hs_bert_bwd(C.byref(desc), ctx.ids.data_ptr(), rt.p(ctx.mask), dy.data_ptr(), saved.data_ptr(),
                                     saved.numel(), ws.data_ptr(), ws.numel(), rt.stream()), "hs_bert_bwd")
         ctx.saved_buf = None
+        if ctx.counted is not None:
+            ctx.counted.finish()
         return (None, None, None, *views())
 
 
