@@ -108,9 +108,18 @@ def test_wgrad_gemm_row_sums_are_the_bias_gradient(cfg):
             assert torch.equal(db.cpu().double(), dY[:, :out_f].double().sum(0)), (cfg, rows, out_f, in_f)
     finally:
         lib.hs_gemm_debug(-1, 0)
-    with pytest.raises(L.HamspineError, match="rowsum_a"):
+    # K-contiguous operands (dY^T, X^T: the transposed-operand weight gradient of the BERT layers) produce the row sums too
+    for rows, out_f, in_f in ((320, 72, 40), (4096, 768, 768), (136, 200, 264)):
+        dYt = _rand((out_f, rows), torch.bfloat16, True, 7)
+        Xt = _rand((in_f, rows), torch.bfloat16, True, 8)
+        dW = torch.full((out_f, in_f), float("nan"), dtype=torch.float32, device=DEV)
+        db = torch.full((out_f,), float("nan"), dtype=torch.float32, device=DEV)
+        raw.gemm(dYt.to(DEV), Xt.to(DEV), dW, out_f, in_f, rows, a_kind=L.A_KC, b_kind=L.B_KC, lda=rows, ldb=rows, rowsum_a=db)
+        assert torch.equal(dW.cpu().double(), dYt.double() @ Xt.double().t()), (rows, out_f, in_f)
+        assert torch.equal(db.cpu().double(), dYt.double().sum(1)), (rows, out_f, in_f)
+    with pytest.raises(L.HamspineError, match="rowsum_a"):     # mixed layouts have no row-sum variant
         A = _rand((64, 64), torch.bfloat16, True, 1).to(DEV)
-        raw.gemm(A, A, torch.empty(64, 64, device=DEV), 64, 64, 64, a_kind=L.A_KC, b_kind=L.B_KC, lda=64, ldb=64,
+        raw.gemm(A, A, torch.empty(64, 64, device=DEV), 64, 64, 64, a_kind=L.A_KC, b_kind=L.B_RC, lda=64, ldb=64,
                  rowsum_a=torch.empty(64, device=DEV))
 
 
