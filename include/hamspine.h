@@ -82,8 +82,9 @@ typedef struct hs_gemm_params {
     /* batching: blockIdx.z = b; operand offset = (b / batch_inner)*bs0 + (b % batch_inner)*bs1 */
     int32_t batch, batch_inner;
     int64_t a_bs0, a_bs1, b_bs0, b_bs1, d_bs0, d_bs1;
-    /* split-K (batch must be 1): partial sums go to `splitk_ws` (f32, split*M*N) and are
-       reduced by a second kernel that applies the epilogue. 0/1 = off. */
+    /* split-K (batch must be 1): partial sums go to `splitk_ws` (f32, hs_gemm_splitk_ws_bytes(p) bytes: one M*N slab per
+       slice plus, beyond 8 slices, one per group of 8).  bf16: reduced inside the launch (two-level last-arriver hand-off,
+       fixed summation order) before the epilogue; f32: by a second kernel that applies the epilogue.  0/1 = off. */
     int32_t split_k;
     float* splitk_ws;
     /* epilogue */

@@ -160,7 +160,7 @@ static int gemm_splitk(Run& r, hs_gemm_params& p) {
     const int split = hs_gemm_suggest_split(p.M, p.N, p.K, p.dtype);
     const long long mk = r.ws.mark();
     p.split_k = split;
-    if (split > 1) p.splitk_ws = (float*)r.ws.alloc((long long)split * p.M * p.N * 4);
+    if (split > 1) p.splitk_ws = (float*)r.ws.alloc(hs_gemm_splitk_ws_bytes(&p));
     if (!r.plan) {
         if (r.ws.overflow) {
             set_error("gemm_splitk: workspace too small");
@@ -549,6 +549,9 @@ static int conv_dgrad_run(Run& r, const ConvShape& s, const void* dy, const void
     } else {
         p.a_kind = HS_A_DGRAD; p.b_kind = HS_B_WDGRAD; p.g = geom_of(s);
     }
+    // late layers: few output tiles under a long K (7x7 maps: 200 tiles x 72 K tiles) -- split-K, reduced inside the launch
+    // with the full epilogue (the parity-ordered stride-2 walk has its own K schedule and stays whole)
+    if (r.dt == HS_BF16 && s.stride == 1) return gemm_splitk(r, p);
     CALL(r, gemm_impl(&p, r.s));
     return HS_OK;
 }

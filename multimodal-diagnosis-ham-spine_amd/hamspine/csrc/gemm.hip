@@ -326,7 +326,8 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
         a.k_per_split = ceil_div(ktiles, split) * kb_cfg;
         a.splitk_ws = p->splitk_ws;
         // bf16: the last-arriving slice of a tile reduces it inside the launch; f32 (parity mode) keeps the second pass
-        if (bf16 && a.tiles_m * a.tiles_n <= kTicketPool && (long long)split * p->M * p->N * 4 < 0x7fffff00ll) {
+        const long long ngroups = (split + kSplitGroup - 1) / kSplitGroup;
+        if (bf16 && (long long)a.tiles_m * a.tiles_n * (1 + ngroups) <= kTicketPool && splitk_slabs(split) * p->M * p->N * 4 < 0x7fffff00ll) {
             a.tickets = ticket_pool(stream);
             HS_REQUIRE(a.tickets != nullptr, "hs_gemm: cannot allocate the split-K arrival counters");
         }
@@ -487,7 +488,7 @@ hs_status hs_gemm(const hs_gemm_params* p, void* stream) { return hs::gemm_impl(
 int32_t hs_gemm_stat_rows(const hs_gemm_params* p) { return hs::gemm_stat_rows(p); }
 int64_t hs_gemm_splitk_ws_bytes(const hs_gemm_params* p) {
     if (!p || p->split_k <= 1) return 0;
-    return (int64_t)p->split_k * p->M * p->N * 4;
+    return (int64_t)hs::splitk_slabs(p->split_k) * p->M * p->N * 4;   // slice slabs + the group slabs of the in-launch reduction
 }
 int32_t hs_gemm_suggest_split(int32_t M, int32_t N, int32_t K, int32_t dtype) {
     const int bk = dtype == HS_BF16 ? 64 : 32;
@@ -502,7 +503,12 @@ int32_t hs_gemm_suggest_split(int32_t M, int32_t N, int32_t K, int32_t dtype) {
     long long s = (units + tiles - 1) / tiles;   // 256/384/768 work units measured the same on C2 with the separate reduce pass
     const long long smax = ktiles / 8 > 0 ? ktiles / 8 : 1;   // keep >= 8 k-tiles per split
     if (s > smax) s = smax;
-    if (s > 64) s = 64;
+    static const long long cap = [] {            // measurement: HAMSPINE_SPLIT_MAX overrides the largest split
+        const char* e = getenv("HAMSPINE_SPLIT_MAX");
+        const long long v = e ? atoll(e) : 0;
+        return v > 0 ? v : 64ll;
+    }();
+    if (s > cap) s = cap;
     return (int32_t)(s < 1 ? 1 : s);
 }
 }

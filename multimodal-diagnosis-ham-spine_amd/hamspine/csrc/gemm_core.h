@@ -475,6 +475,19 @@ __device__ __forceinline__ void mask_tail(u32x4& c, int nvalid) {
     }
 }
 
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// in-launch split-K: slices hand their slabs off in groups of this many (gemm_bf16_kernel); the workspace holds one slab per
+// slice plus, for more than one group, one per group
+constexpr int kSplitGroup = 8;
+inline long long splitk_slabs(int split) { return split <= kSplitGroup ? split : split + (split + kSplitGroup - 1) / kSplitGroup; }
+
 constexpr bool a_is_rc(int k) { return k == HS_A_RC; }
 constexpr bool b_is_rc(int k) { return k != HS_B_KC; }
 
@@ -950,71 +963,137 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
     }
     if (split_k > 1) {
         // In-launch split-K reduction (the separate splitk_reduce pass cost 65 launches / 0.63 ms per C2 step).
-        // Protocol (cdna_hip_programming.md, "In-launch split-K reduction" / Guideline 16, counter form):
-        //   every slice workgroup: slab stores WRITE-THROUGH (sc1: the bytes leave this XCD's L2, so no release fence)
-        //   -> every wave s_waitcnt vmcnt(0) -> workgroup barrier -> ONE lane: relaxed agent-scope ticket add;
-        //   the workgroup that draws split_k - 1 is the reducer: one agent-scope acquire (drops this CU's stale L1 lines)
-        //   -> vmcnt(0) -> barrier -> all waves read every slice's slab in slice order (fixed order: deterministic sum,
-        //   whichever slice arrived last) -> re-zero the ticket for the next launch -> the normal epilogue.
-        // Placement independent: nothing depends on which XCD / CU a slice runs on or in which order slices finish.
-        const __amdgpu_buffer_rsrc_t rsW = make_rsrc(splitk_ws, (unsigned)min((unsigned long long)split_k * argM * argN * 4ull, 0x7fffff00ull));
+        // Protocol of one hand-off (cdna_hip_programming.md, "In-launch split-K reduction" / Guideline 16, counter form):
+        //   producers: slab stores WRITE-THROUGH (sc1: the bytes leave this XCD's L2, so no release fence) -> every wave
+        //   s_waitcnt vmcnt(0) -> workgroup barrier -> ONE lane: relaxed agent-scope ticket add; the workgroup whose add comes
+        //   last is the consumer: one agent-scope acquire (drops this CU's stale L1 lines) -> vmcnt(0) -> barrier -> all
+        //   waves read the slabs in a fixed order -> re-zero the ticket for the next launch.
+        // Two levels: the consumer of a hand-off is alone on its tile while everyone else has retired, so its slab reads are
+        // the tail of the launch, one memory round trip per batch of loads (a 64-way split read slab after slab by one
+        // workgroup measured 60+ us of tail on a 30 us stream).  Slices therefore hand off in GROUPS of kSplitGroup (8)
+        // consecutive slices; the last slice of a group sums that group (one batch) and publishes the group's slab; the last
+        // GROUP of a tile sums the <= 8 group slabs and runs the epilogue.  The tail is two batches deep instead of split_k
+        // slabs, and the sum has one fixed association (slices in order inside a group, groups in order): deterministic
+        // whichever slice arrives last.  Placement independent: nothing depends on where or in which order slices run.
+        constexpr int NF = FM * FN;
+        // slabs whose loads are in flight together (12-16 loads per lane): about what fits in the registers the K loop's
+        // operand fragments have just vacated -- registers beyond the K loop's own need lower the occupancy of EVERY launch of
+        // the kernel (8 / 4 / 2 slabs measured: 202-256 VGPRs instead of 79-176 and the whole family 11 % slower)
+        constexpr int U = NF <= 4 ? 3 : NF <= 8 ? 2 : 1;
+        static_assert(NF % 4 == 0 && U * NF <= 60, "slab loads in flight: the vmcnt field holds 6 bits");
+        const int ngroups = (split_k + kSplitGroup - 1) / kSplitGroup;
+        const int nslabs = split_k + (ngroups > 1 ? ngroups : 0);     // slice slabs, then group slabs
+        const unsigned ws_bytes = (unsigned)min((unsigned long long)nslabs * argM * argN * 4ull, 0x7fffff00ull);
+        const __amdgpu_buffer_rsrc_t rsW = make_rsrc(splitk_ws, ws_bytes);
+        const unsigned long long wsa = (unsigned long long)splitk_ws;
+        const u32x4 rsw = {(unsigned)wsa, (unsigned)(wsa >> 32) & 0xffffu, ws_bytes, 0x00020000u};
         const bool vecw = (argN & 3) == 0;
+        const unsigned slab = (unsigned)((long long)argM * argN * 4);
+        unsigned eoff[NF];                                           // byte offset of this lane's fragment f inside a slab
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const int m = m0 + wm * WM + i * 16 + l15;
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 const int n = n0 + wn * WN + j * 16 + 4 * g;
-                if (m < argM && n < argN) {
-                    const unsigned off = (unsigned)((((long long)z * argM + m) * argN + n) * 4);
-                    if (vecw) {
-                        const u32x4 v = {__float_as_uint(acc[i][j][0]), __float_as_uint(acc[i][j][1]),
-                                         __float_as_uint(acc[i][j][2]), __float_as_uint(acc[i][j][3])};
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rsW, off, 0, 16 /* sc1: write-through */);
-                    } else {
-                        for (int e = 0; e < 4 && n + e < argN; ++e)
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][e]), rsW, off + 4 * e, 0, 16);
-                    }
-                }
+                eoff[i * FN + j] = (m < argM && n < argN) ? (unsigned)(((long long)m * argN + n) * 4) : kOOB;
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its own stores
-        __syncthreads();
-        unsigned* ticket = a.tickets + (tm * a.tiles_n + tn);
-        int* flag = (int*)smem;                                   // the operand ring is free by now
-        if (tid == 0) *flag = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (*flag != split_k - 1) {
-            HS_STAMP(4);
-            return;                                               // (workgroup-uniform)
-        }
-        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        int* flag = (int*)smem;                                      // the operand ring is free by now
+        auto publish = [&](int slab_idx, unsigned* ticket) -> int {  // store acc as slab `slab_idx`, arrive; returns the ticket drawn
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+            for (int f = 0; f < NF; ++f) {
+                if (eoff[f] == kOOB) continue;
+                const unsigned off = (unsigned)slab_idx * slab + eoff[f];
+                const f32x4& v4 = acc[f / FN][f % FN];
+                if (vecw) {
+                    const u32x4 v = {__float_as_uint(v4[0]), __float_as_uint(v4[1]), __float_as_uint(v4[2]), __float_as_uint(v4[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsW, off, 0, 16 /* sc1: write-through */);
+                } else {
+                    const int n = n0 + wn * WN + (f % FN) * 16 + 4 * g;
+                    for (int e = 0; e < 4 && n + e < argN; ++e)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v4[e]), rsW, off + 4 * e, 0, 16);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its own stores
+            __syncthreads();
+            if (tid == 0) *flag = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const int drawn = *flag;
+            __syncthreads();                                          // the flag word is reused by the next hand-off
+            return drawn;
+        };
+        auto gather = [&](int first, int count) {                    // acc = slab[first] + slab[first + 1] + ... (in order)
+            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
 #pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int sidx = 0; sidx < split_k; ++sidx) {
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int m = m0 + wm * WM + i * 16 + l15;
+                for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (vecw) {
+                // The compiler will not keep more than a few of these loads in flight on its own (it serialises them against
+                // the dependent adds to save registers), so the loads and their COUNTED waits are spelled out: slab u is
+                // added once at most (U - 1 - u) slabs' loads are still outstanding.  Slabs past `count` read as zeros.
+                for (int s0 = 0; s0 < count; s0 += U) {
+                    u32x4 x[U][NF];
 #pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    const int n = n0 + wn * WN + j * 16 + 4 * g;
-                    if (m < argM && n < argN) {
-                        const HS_GLOBAL float* w = (const HS_GLOBAL float*)splitk_ws + ((long long)sidx * argM + m) * argN + n;
-                        if (vecw) {
-                            const f32x4 x = *(const HS_GLOBAL f32x4*)w;
-                            acc[i][j] += x;
-                        } else {
-                            for (int e = 0; e < 4 && n + e < argN; ++e) acc[i][j][e] += w[e];
+                    for (int u = 0; u < U; ++u) {
+                        const bool live = s0 + u < count;
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) {
+                            const unsigned off = (live && eoff[f] != kOOB) ? (unsigned)(first + s0 + u) * slab + eoff[f] : kOOB;
+                            if constexpr (U == 1) x[u][f] = buf_load16(rsW, off);      // one slab: the compiler's own schedule will do
+                            else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(x[u][f]) : "v"(off), "s"(rsw) : "memory");
                         }
                     }
+                    static_for<0, U>([&](auto uc) {
+                        constexpr int u = decltype(uc)::value;
+                        if constexpr (U > 1) {
+#pragma unroll
+                            for (int f = 0; f < NF; f += 4)
+                                asm volatile("s_waitcnt vmcnt(%4)"
+                                             : "+v"(x[u][f]), "+v"(x[u][f + 1]), "+v"(x[u][f + 2]), "+v"(x[u][f + 3])
+                                             : "n"((U - 1 - u) * NF));
+                        }
+#pragma unroll
+                        for (int f = 0; f < NF; ++f)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[f / FN][f % FN][e] += __uint_as_float(x[u][f][e]);
+                    });
+                }
+            } else {
+                for (int sidx = first; sidx < first + count; ++sidx) {
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        if (eoff[f] == kOOB) continue;
+                        const int n = n0 + wn * WN + (f % FN) * 16 + 4 * g;
+                        const HS_GLOBAL float* w = (const HS_GLOBAL float*)((const HS_GLOBAL char*)splitk_ws + (long long)sidx * slab + eoff[f]);
+                        for (int e = 0; e < 4 && n + e < argN; ++e) acc[f / FN][f % FN][e] += w[e];
+                    }
                 }
             }
+        };
+        // level 0: the slices of a group (of the whole tile when there is one group); level 1: the groups of the tile.  One
+        // copy of the code, walked once or twice (emitted twice it held both levels' registers: 231 instead of 149 VGPRs).
+        const int tile_id = tm * a.tiles_n + tn;
+        const int grp = z / kSplitGroup;
+        int slab_idx = z, first = ngroups > 1 ? grp * kSplitGroup : 0;
+        int count = ngroups > 1 ? min(kSplitGroup, split_k - first) : split_k;
+        unsigned* ticket = ngroups > 1 ? a.tickets + a.tiles_m * a.tiles_n + tile_id * ngroups + grp : a.tickets + tile_id;
+#pragma unroll 1
+        for (int level = ngroups > 1 ? 0 : 1; level < 2; ++level) {
+            if (publish(slab_idx, ticket) != count - 1) {
+                HS_STAMP(4);
+                return;                                               // (workgroup-uniform)
+            }
+            gather(first, count);
+            if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            slab_idx = split_k + grp;
+            first = split_k;
+            count = ngroups;
+            ticket = a.tickets + tile_id;
         }
-        if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // whole tile inside the matrix and 4-wide storable: one of the feature sets the training / inference steps use gets
     // branch-free code; anything else (edge tiles, rare combinations) takes the generic body

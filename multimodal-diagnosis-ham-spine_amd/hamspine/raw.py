@@ -69,7 +69,7 @@ def gemm(A, B, D, M, N, K, a_kind=L.A_KC, b_kind=L.B_KC, lda=0, ldb=0, ldd=None,
     p.split_k = split_k
     ws = None
     if split_k > 1:
-        ws = torch.empty(split_k * M * N, dtype=torch.float32, device=A.device)
+        ws = torch.empty(int(L.lib().hs_gemm_splitk_ws_bytes(C.byref(p))) // 4, dtype=torch.float32, device=A.device)
         p.splitk_ws = ptr(ws)
     p.D = ptr(D)
     p.ldd = N if ldd is None else ldd

@@ -230,10 +230,14 @@ def test_conv_fwd_dgrad_wgrad(dtype, case):
 
 
 @pytest.mark.parametrize("kind,M,N,K,split", [("tn", 768, 768, 4096, 4), ("tn", 256, 64, 12800, 16), ("nt", 512, 768, 3072, 3),
-                                               ("nn", 320, 200, 2048, 2), ("tn", 104, 72, 5000, 5)])
+                                               ("nn", 320, 200, 2048, 2), ("tn", 104, 72, 5000, 5),
+                                               # two-level hand-off: groups of 8 slices (full, ragged last group, 128x64 tiles)
+                                               ("tn", 256, 64, 100352, 64), ("tn", 200, 72, 20000, 13), ("nt", 256, 1024, 8192, 20),
+                                               ("nn", 1568, 512, 2048, 9)])
 def test_splitk_in_launch_reduction(kind, M, N, K, split):
-    """bf16 split-K reduces inside the launch (the slice workgroup that arrives last sums the slabs in slice order and runs
-    the epilogue; no second pass): equal to the unsplit GEMM up to f32 summation order, bit-identical from launch to launch
+    """bf16 split-K reduces inside the launch (slices hand their slabs off in groups of 8: the last slice of a group sums the
+    group in slice order, the last group of a tile sums the group slabs and runs the epilogue; no second pass): equal to the
+    unsplit GEMM up to f32 summation order, bit-identical from launch to launch
     (the sum order does not depend on which slice arrives last), repeatable back to back on one stream (the arrival
     counters re-zero themselves), and on two streams at once (each stream has its own counters)."""
     g = torch.Generator().manual_seed(M + N + K)
