@@ -154,8 +154,12 @@ def roofline_by_class(path, steps):
                 nbytes = 2.0 * (M * N + N * K) + 2.0 * M * K / (R * R) / (stride * stride)    # dy read once
             elif combo == 5:
                 nbytes = 2.0 * (M * K + N * K / (R * R) * stride * stride) + 4.0 * M * N
+            name = shape_class(combo, M, N, K, R)
+            if combo >= 6:                            # grouped weight gradients of the image tower: M problems in one grid
+                nbytes = float(r[12])
+                name = "pointwise_wgrad_grouped" if combo == 6 else "conv_wgrad_grouped"
             bound = "mfma" if flop / nbytes >= RIDGE_FLOP_PER_BYTE else "hbm"
-            a = agg.setdefault((shape_class(combo, M, N, K, R), bound), {"launches": 0, "ms": 0.0, "flop": 0.0, "bytes": 0.0})
+            a = agg.setdefault((name, bound), {"launches": 0, "ms": 0.0, "flop": 0.0, "bytes": 0.0})
             a["launches"] += 1
             a["ms"] += ms
             a["flop"] += flop

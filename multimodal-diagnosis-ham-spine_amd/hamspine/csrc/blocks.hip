@@ -21,6 +21,10 @@ __global__ __launch_bounds__(256) void gather3_kernel(const float* __restrict__ 
 
 int gemm_impl(const hs_gemm_params* p, hipStream_t stream);
 int gemm_stat_rows(const hs_gemm_params* p);
+struct GemmGroup;
+GemmGroup* gemm_group_open(hipStream_t s, int slot);
+int gemm_group_add(GemmGroup* g, const hs_gemm_params* p, hipStream_t s);
+int gemm_group_flush(GemmGroup* g, hipStream_t s);
 int attention_bwd_fused(const hs_attn_desc& d, const void* q, const void* k, const void* v, const void* dO, void* dq, void* dk,
                         void* dv, const void* P, int ldP, hipStream_t s);
 int attention_fwd_fused(const hs_attn_desc& d, const void* q, const void* k, const void* v, void* o, void* P, void* Pd, int ldP,
@@ -55,6 +59,10 @@ struct Run {
     // forked behind the producers of its inputs and joined before the composite returns
     hipStream_t side = nullptr;
     bool side_used = false;
+    // tower backward: weight-gradient GEMMs are collected here and launched as grouped grids when the tower's data-gradient
+    // chain is done (their operands -- saved activations and the ws gradients, which are then not released -- stay alive)
+    bool defer_wgrad = false;
+    GemmGroup *grp_pw = nullptr, *grp_conv = nullptr;
 };
 
 // one non-blocking side stream and a ring of events per device (events are re-recordable; every composite joins
@@ -156,18 +164,21 @@ static hs_gemm_params gemm_defaults(int dt) {
     return p;
 }
 // wgrad-style GEMMs reduce over a long K into a small output: pick split-K, borrow slabs from ws.
-static int gemm_splitk(Run& r, hs_gemm_params& p) {
+static int gemm_splitk(Run& r, hs_gemm_params& p, bool may_defer = false) {
     const int split = hs_gemm_suggest_split(p.M, p.N, p.K, p.dtype);
     const long long mk = r.ws.mark();
     p.split_k = split;
     if (split > 1) p.splitk_ws = (float*)r.ws.alloc(hs_gemm_splitk_ws_bytes(&p));
+    const bool defer = may_defer && r.defer_wgrad && p.dtype == HS_BF16;
     if (!r.plan) {
         if (r.ws.overflow) {
             set_error("gemm_splitk: workspace too small");
             return HS_ERR_ARG;
         }
-        HS_PROPAGATE(gemm_impl(&p, r.s));
+        if (defer) HS_PROPAGATE(gemm_group_add(p.b_kind == HS_B_CONV ? r.grp_conv : r.grp_pw, &p, r.s));
+        else HS_PROPAGATE(gemm_impl(&p, r.s));
     }
+    if (defer) return HS_OK;                 // the slabs stay allocated until the grouped launch has run
     // with a side stream, slabs of consecutive GEMMs may be live concurrently: keep them until the composite ends
     if (r.plan ? !overlap_enabled() : !r.side) r.ws.release(mk);
     return HS_OK;
@@ -483,6 +494,14 @@ static bool fused_ln_bwd_enabled() {        // HAMSPINE_FUSED_LN_BWD=0: separate
     }
     return v == 1;
 }
+static bool grouped_wgrad_enabled() {     // HAMSPINE_GROUPED_WGRAD=0: the tower backward launches every weight gradient on its own
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("HAMSPINE_GROUPED_WGRAD");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
 static bool fused_bn_stats_enabled() {     // HAMSPINE_FUSED_BN_STATS=0: BatchNorm makes its own statistics pass
     static int v = -1;
     if (v < 0) {
@@ -568,7 +587,7 @@ static int conv_wgrad_run(Run& r, const ConvShape& s, const void* dy, const void
     } else {
         p.b_kind = HS_B_CONV; p.g = geom_of(s);
     }
-    return gemm_splitk(r, p);
+    return gemm_splitk(r, p, true);
 }
 
 // weights in the compute dtype: f32 mode reads the parameters directly, bf16 mode casts them into
@@ -1255,6 +1274,15 @@ static int resnet_bwd_run(Run& r, const hs_resnet_desc& d, const void* const* dy
     int cur = 0;
     const void* dy = nullptr;
     int tap = d.n_taps - 1;
+    // bf16: the blocks' weight-gradient GEMMs are not launched where they occur but collected and run as two grouped grids
+    // (1x1 / spatial filters) behind the data-gradient chain; the blocks' scratch is then kept to the end (HAMSPINE_GROUPED_WGRAD=0:
+    // one launch per convolution, scratch released per block)
+    r.defer_wgrad = dt == HS_BF16 && grouped_wgrad_enabled() && !overlap_enabled();
+    if (r.defer_wgrad && !r.plan) {
+        r.grp_pw = gemm_group_open(r.s, 0);
+        r.grp_conv = gemm_group_open(r.s, 1);
+        HS_REQUIRE(r.grp_pw && r.grp_conv, "resnet_bwd: cannot set up the grouped weight-gradient launches");
+    }
     for (int i = d.n_blocks - 1; i >= 0; --i) {
         const bool is_tap = tap >= 0 && d.tap_block[tap] == i;
         const void* ext = is_tap && dy_taps ? dy_taps[tap] : nullptr;
@@ -1272,10 +1300,15 @@ static int resnet_bwd_run(Run& r, const hs_resnet_desc& d, const void* const* dy
         r.saved.off = lo.lay_off[i + 1];
         const long long wm = r.ws.mark();
         HS_PROPAGATE(resblock_bwd_run(r, d.blocks[i], x, y, dy, dx));
-        r.ws.release(wm);
+        if (!r.defer_wgrad) r.ws.release(wm);
         dy = dx;
         cur ^= 1;
     }
+    if (r.defer_wgrad && !r.plan) {
+        HS_PROPAGATE(gemm_group_flush(r.grp_pw, r.s));
+        HS_PROPAGATE(gemm_group_flush(r.grp_conv, r.s));
+    }
+    r.defer_wgrad = false;
     const hs_conv_bn& cb = d.stem.cb;
     if (cb.dw || cb.dgamma || cb.dbeta) {
         r.saved.off = lo.lay_off[0];

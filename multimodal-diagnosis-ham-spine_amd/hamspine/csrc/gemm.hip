@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <math.h>
 #include <map>
+#include <tuple>
 #include "gemm_launch.h"
 
 namespace hs {
@@ -34,6 +35,7 @@ struct ProfRec {
     double flops;
     int cls;
     int M, N, K, combo, cfg, split, batch, conv_r, conv_stride;
+    double bytes = 0;     // grouped launches: algorithmic bytes of all their problems (single launches: derived from the shape)
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -128,7 +130,15 @@ int gemm_stat_rows(const hs_gemm_params* p) {
     return ceil_div(p->M, cfg == CFG_64x64 ? 64 : (cfg == CFG_256x128 || cfg == CFG_256x128x32) ? 256 : 128);
 }
 
-int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
+// everything gemm_impl decides before the launch
+struct Prepared {
+    GemmArgs a;
+    int cfg, combo, split, batch;
+    bool bf16, conv, vec;
+    dim3 grid;
+    double flops;
+};
+static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q) {
     HS_REQUIRE(p != nullptr, "hs_gemm: null params");
     HS_REQUIRE(p->dtype == HS_F32 || p->dtype == HS_BF16, "hs_gemm: bad dtype %d", p->dtype);
     HS_REQUIRE(p->M > 0 && p->N > 0 && p->K >= 0, "hs_gemm: bad dims %d %d %d", p->M, p->N, p->K);
@@ -291,10 +301,11 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     if (p->rowsum_a && p->a_kind == HS_A_KC && cfg != CFG_128x64 && cfg != CFG_64x64) cfg = CFG_128x64;   // instantiated tiles of the RS variant
     if (g_dbg_cfg >= 0 && g_dbg_cfg <= CFG_64x64 && cfg != CFG_STEM) cfg = g_dbg_cfg;
     if (g_dbg_cfg >= CFG_256x128 && g_dbg_cfg <= CFG_256x128x32 && bf16 && !conv) cfg = g_dbg_cfg;
+    if (cfg == CFG_128x128x32 && split > 1) cfg = CFG_128x128;      // the three-workgroups-per-CU kernel has no split-K code
     // (A deeper operand ring -- 5 / 8 slots for the long-K split weight gradients of the convolutions -- was built and
     // measured: 1.93 vs 1.92 ms per step on the 1x1 weight gradients, 0.70 vs 0.52 ms on the 3x3 ones, where the larger LDS
     // footprint costs a resident workgroup.  The kernel keeps the ring depth as a template parameter; 3 is what runs.)
-    const int ring = 3;
+    const int ring = cfg == CFG_128x128x32 ? HS_W3_RING : 3;
     int BM = 64, BN = 64;
     if (cfg == CFG_128x128 || cfg == CFG_128x128x32) { BM = 128; BN = 128; }
     else if (cfg == CFG_256x128 || cfg == CFG_256x128x32) { BM = 256; BN = 128; }
@@ -366,8 +377,6 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
         }
     }
     dim3 grid(a.tiles_m * a.tiles_n, 1, split > 1 ? split : batch);
-    int st;
-    ProfRec rec;
     double flops = 2.0 * p->M * p->N * (double)p->K * batch;
     if (a.parity) {   // strided dgrad: only the (pixel parity, filter tap) pairs that reach an output pixel are real work
         int kept = 0;
@@ -377,7 +386,24 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
                     kept += ((((c >> 1) + p->g.pad - r) & 1) == 0 && (((c & 1) + p->g.pad - q) & 1) == 0) ? 1 : 0;
         flops *= (double)kept / (4.0 * p->g.R * p->g.S);
     }
-    const bool timed = prof_begin(stream, flops, (bf16 ? 0 : 2) + (conv ? 1 : 0), rec);
+    q.a = a;
+    q.cfg = cfg; q.combo = combo; q.split = split; q.batch = batch;
+    q.bf16 = bf16; q.conv = conv; q.vec = vec;
+    q.grid = grid;
+    q.flops = flops;
+    return HS_OK;
+}
+
+int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
+    Prepared q;
+    HS_PROPAGATE(gemm_prepare(p, stream, q));
+    const GemmArgs& a = q.a;
+    const int cfg = q.cfg, combo = q.combo, split = q.split, batch = q.batch;
+    const bool bf16 = q.bf16, conv = q.conv, vec = q.vec;
+    const dim3 grid = q.grid;
+    int st;
+    ProfRec rec;
+    const bool timed = prof_begin(stream, q.flops, (bf16 ? 0 : 2) + (conv ? 1 : 0), rec);
     if (bf16) st = conv ? launch_bf16_conv(cfg, combo, a, grid, stream) : launch_bf16_plain(cfg, combo, a, grid, stream);
     else st = conv ? launch_f32_conv(cfg, combo, a, grid, stream) : launch_f32_plain(cfg, combo, vec, a, grid, stream);
     if (timed) {
@@ -393,6 +419,111 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
         else hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, a);
         HS_LAUNCH_CHECK();
     }
+    return HS_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// grouped launches (gemm_bf16_grouped_kernel): problems are collected with gemm_group_add and launched as one grid by
+// gemm_group_flush.  A group object belongs to one (device, stream, slot) and keeps its device-side table between steps:
+// a training step adds the same problems with the same pointers every time, so the table is uploaded once.
+// ------------------------------------------------------------------------------------------------
+struct GemmGroup {
+    int combo = -1;
+    std::vector<GemmArgs> items;
+    std::vector<int> first;
+    int total = 0, ticket_off = 0;
+    double flops = 0, bytes = 0;
+    char* dev = nullptr;
+    size_t dev_cap = 0;
+    std::vector<char> shadow;      // what the device table holds
+};
+static constexpr int kGroupMax = 64;
+GemmGroup* gemm_group_open(hipStream_t s, int slot) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, hipStream_t, int>, GemmGroup*> groups;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    GemmGroup*& g = groups[std::make_tuple(dev, s, slot)];
+    if (!g) g = new GemmGroup();
+    g->combo = -1;
+    g->items.clear();
+    g->first.clear();
+    g->total = 0;
+    g->ticket_off = 0;
+    g->flops = g->bytes = 0;
+    return g;
+}
+int gemm_group_flush(GemmGroup* g, hipStream_t s) {
+    if (!g || g->items.empty()) return HS_OK;
+    const int n = (int)g->items.size();
+    constexpr size_t kHead = 512;                                   // first_wg[0..64] and padding
+    const size_t bytes = kHead + (size_t)n * sizeof(GemmArgs);
+    std::vector<char> host(bytes, 0);
+    int* fw = (int*)host.data();
+    for (int i = 0; i < n; ++i) fw[i] = g->first[i];
+    fw[n] = g->total;
+    memcpy(host.data() + kHead, g->items.data(), (size_t)n * sizeof(GemmArgs));
+    if (host != g->shadow) {
+        // rare (first step, or an arena moved): the previous launch of this group may still be reading the table
+        static const bool dbg = [] { const char* e = getenv("HAMSPINE_GROUP_DEBUG"); return e && e[0] == '1'; }();
+        if (dbg) {
+            size_t diff = 0;
+            for (size_t i = 0; i < std::min(host.size(), g->shadow.size()); ++i) diff += host[i] != g->shadow[i];
+            fprintf(stderr, "[group] table upload: %d problems, %zu bytes (%zu before), %zu bytes differ\n", n, bytes, g->shadow.size(), diff);
+        }
+        HS_CHECK_HIP(hipStreamSynchronize(s));
+        if (bytes > g->dev_cap) {
+            if (g->dev) (void)hipFree(g->dev);
+            g->dev = nullptr;
+            g->dev_cap = 0;
+            HS_CHECK_HIP(hipMalloc(&g->dev, bytes * 2));
+            g->dev_cap = bytes * 2;
+        }
+        HS_CHECK_HIP(hipMemcpy(g->dev, host.data(), bytes, hipMemcpyHostToDevice));
+        g->shadow.swap(host);
+    }
+    ProfRec rec;
+    const bool timed = prof_begin(s, g->flops, g->combo == 5 ? 1 : 0, rec);
+    const int st = g->combo == 5 ? launch_bf16_grouped_conv(5, (const GemmArgs*)(g->dev + kHead), (const int*)g->dev, n, g->total, s)
+                                 : launch_bf16_grouped_plain(2, (const GemmArgs*)(g->dev + kHead), (const int*)g->dev, n, g->total, s);
+    if (timed) {
+        rec.M = n; rec.N = 0; rec.K = 0; rec.combo = g->combo == 5 ? 7 : 6; rec.cfg = CFG_64x64; rec.split = 0; rec.batch = 1;
+        rec.conv_r = 0; rec.conv_stride = 0;
+        rec.bytes = g->bytes;
+        prof_end(s, rec);
+    }
+    g->combo = -1;
+    g->items.clear();
+    g->first.clear();
+    g->total = 0;
+    g->ticket_off = 0;
+    g->flops = g->bytes = 0;
+    return st;
+}
+// adds p to the group, or launches it on its own when it cannot be grouped (f32, another layout or tile, no in-launch reduce)
+int gemm_group_add(GemmGroup* g, const hs_gemm_params* p, hipStream_t s) {
+    if (!g) return gemm_impl(p, s);
+    Prepared q;
+    HS_PROPAGATE(gemm_prepare(p, s, q));
+    const bool ok = q.bf16 && q.cfg == CFG_64x64 && (q.combo == 2 || q.combo == 5) && q.batch == 1 && !q.a.stamps &&
+                    (q.split == 1 || q.a.tickets != nullptr) && !q.a.rowsum[0] && !q.a.colstats;
+    if (!ok) return gemm_impl(p, s);
+    const long long ngroups = q.split > 1 ? (q.split + kSplitGroup - 1) / kSplitGroup : 0;
+    const long long need = q.split > 1 ? (long long)q.a.tiles_m * q.a.tiles_n * (1 + (ngroups > 1 ? ngroups : 0)) : 0;
+    if (!g->items.empty() && (g->combo != q.combo || (int)g->items.size() >= kGroupMax || g->ticket_off + need > kTicketPool))
+        HS_PROPAGATE(gemm_group_flush(g, s));
+    if (need > kTicketPool) return gemm_impl(p, s);
+    g->combo = q.combo;
+    if (q.split > 1) q.a.tickets += g->ticket_off;
+    g->ticket_off += (int)need;
+    g->first.push_back(g->total);
+    g->total += (int)(q.grid.x * q.grid.z);
+    g->items.push_back(q.a);
+    g->flops += q.flops;
+    const double R2 = q.conv ? (double)p->g.R * p->g.S : 1.0, st2 = q.conv ? (double)p->g.stride * p->g.stride : 1.0;
+    g->bytes += 2.0 * ((double)p->M * p->K + (double)p->N * p->K / R2 * st2) + 4.0 * (double)p->M * p->N;
     return HS_OK;
 }
 
@@ -458,7 +589,7 @@ hs_status hs_prof_calibrate(void* stream, int32_t n, float* avg_us) {
     *avg_us = (float)(tot / n * 1e3);
     return HS_OK;
 }
-/* Synchronises, appends one CSV line per recorded launch (cls,combo,cfg,M,N,K,batch,split,R,stride,ms,flops) to `path`, clears. */
+/* Synchronises, appends one CSV line per recorded launch (cls,combo,cfg,M,N,K,batch,split,R,stride,ms,flops,bytes; a grouped launch: combo 6 / 7 = grouped tn / conv weight gradients, M = problems in it) to `path`, clears. */
 hs_status hs_prof_dump(const char* path) {
     HS_CHECK_HIP(hipDeviceSynchronize());
     std::lock_guard<std::mutex> lk(hs::g_prof_mu);
@@ -467,8 +598,8 @@ hs_status hs_prof_dump(const char* path) {
     for (auto& r : hs::g_prof) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess)
-            fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.6f,%.0f\n", r.cls, r.combo, r.cfg, r.M, r.N, r.K, r.batch, r.split, r.conv_r,
-                    r.conv_stride, t, r.flops);
+            fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.6f,%.0f,%.0f\n", r.cls, r.combo, r.cfg, r.M, r.N, r.K, r.batch, r.split, r.conv_r,
+                    r.conv_stride, t, r.flops, r.bytes);
         hs::g_prof_pool.emplace_back(r.a, r.b);
     }
     hs::g_prof.clear();

@@ -19,4 +19,16 @@ int launch_bf16_conv(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream
     set_error("launch_bf16_conv: bad cfg/combo %d/%d", cfg, combo);
     return HS_ERR_ARG;
 }
+int launch_bf16_grouped_conv(int combo, const GemmArgs* list, const int* first_wg, int n, int total_wgs, hipStream_t s) {
+    if (combo != 5) {
+        set_error("launch_bf16_grouped_conv: only the weight-gradient layout is grouped (combo %d)", combo);
+        return HS_ERR_ARG;
+    }
+    auto kernel = gemm_bf16_grouped_kernel<HS_A_RC, HS_B_CONV>;
+    constexpr int lds = 3 * 128 * 64 * 2;
+    if (lds_attr_needed((const void*)kernel)) HS_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kernel, dim3(total_wgs), dim3(256), lds, s, list, first_wg, n);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
 }  // namespace hs

@@ -7,7 +7,8 @@ namespace hs {
         case CFG_128x128: L(128, 128, 64, AK, BKD); \
         case CFG_128x64: L(128, 64, 64, AK, BKD);  \
         case CFG_64x64: L(64, 64, 64, AK, BKD);    \
-        case CFG_128x128x32: L(128, 128, 32, AK, BKD); \
+        case CFG_128x128x32:                       \
+            return launch_with_lds(gemm_bf16_kernel_w3<AK, BKD>, a.lds_stages * 256 * 32 * 2, HS_W3_RING * 256 * 32 * 2, a, grid, s); \
         case CFG_256x128x32:                       \
             return launch_with_lds(gemm_bf16_kernel<256, 128, 32, AK, BKD, true, 4>, a.lds_stages * 384 * 32 * 2, 3 * 384 * 32 * 2, a, grid, s, 512); \
         case CFG_256x128:                          \
@@ -34,5 +35,17 @@ int launch_bf16_plain(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStrea
     }
     set_error("launch_bf16_plain: bad cfg/combo %d/%d", cfg, combo);
     return HS_ERR_ARG;
+}
+int launch_bf16_grouped_plain(int combo, const GemmArgs* list, const int* first_wg, int n, int total_wgs, hipStream_t s) {
+    if (combo != 2) {
+        set_error("launch_bf16_grouped_plain: only the (row-contiguous, row-contiguous) layout is grouped (combo %d)", combo);
+        return HS_ERR_ARG;
+    }
+    auto kernel = gemm_bf16_grouped_kernel<HS_A_RC, HS_B_RC>;
+    constexpr int lds = 3 * 128 * 64 * 2;
+    if (lds_attr_needed((const void*)kernel)) HS_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kernel, dim3(total_wgs), dim3(256), lds, s, list, first_wg, n);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
 }
 }  // namespace hs

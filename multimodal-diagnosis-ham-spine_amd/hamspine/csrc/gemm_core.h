@@ -491,14 +491,13 @@ inline long long splitk_slabs(int split) { return split <= kSplitGroup ? split :
 constexpr bool a_is_rc(int k) { return k == HS_A_RC; }
 constexpr bool b_is_rc(int k) { return k != HS_B_KC; }
 
-__device__ __forceinline__ void tile_from_block(const GemmArgs& a, int& tm, int& tn) {
+__device__ __forceinline__ void tile_from_block(const GemmArgs& a, int& tm, int& tn, int bid) {
     // XCD-aware remap: workgroup ids go round-robin over the 8 XCDs, so XCD x is handed the contiguous run of tile
     // ids [x*nwg/8, (x+1)*nwg/8) (bijective for any grid size).  Tile ids walk the output in groups of `group_m` tile
     // rows, m fastest inside a group: the workgroups an XCD runs at one time then cover group_m x (S/group_m) tiles
     // and share group_m A panels and S/group_m B panels through that XCD's L2 (each XCD has its own L2; with plain
     // n-fastest order one XCD streamed the whole B operand once per tile row).
     const int nwg = a.tiles_m * a.tiles_n;
-    const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int gsz = a.group_m * a.tiles_n;
@@ -600,8 +599,9 @@ __device__ __forceinline__ void wait_vm_tiles(int tiles) {       // wait until a
         default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * NDMA) : "memory"); break;
     }
 }
-template <int BM, int BN, int BK, int AK, int BKIND, bool VEC, int WGM = 2, bool RS = false, int NS = 3>
-__global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) {
+// SK: the launch may be a split-K one (false: the slab / hand-off code is left out -- its registers count against every launch).
+template <int BM, int BN, int BK, int AK, int BKIND, bool VEC, int WGM = 2, bool RS = false, int NS = 3, bool SK = true>
+__device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, const int bz) {
     typedef bf16_t T;
     constexpr int ESZ = 2;
     constexpr bool A_RC = a_is_rc(AK), B_RC = b_is_rc(BKIND);
@@ -631,9 +631,9 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
         asm volatile("" ::"s"(q0), "s"(q1), "s"(q2), "s"(q3), "s"(q4), "s"(q5), "s"(q6), "s"(q7), "s"(q8), "s"(q9), "s"(q10),
                      "s"(pa), "s"(pb), "s"(ba), "s"(bb));
     }
-    tile_from_block(a, tm, tn);
+    tile_from_block(a, tm, tn, bx);
     const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.z;
+    const int z = bz;
 
     long long a_boff = 0, b_boff = 0, d_boff = 0;
     int kbeg = 0, kend = a.K;
@@ -858,6 +858,15 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
             load_frags(cur, 1, a1, b1);
             mma(a0, b0);
             mma(a1, b1);
+        } else if constexpr (BM * BN >= 128 * 128) {
+            // big tiles with BK = 32: one fragment set (the second one costs 32-48 registers, which is the difference between
+            // two and three resident workgroups per CU; the other workgroups' MFMAs cover this one's LDS reads)
+            for (int t = 0; t + 1 < ntiles; ++t) {
+                mma(a0, b0);
+                next_tile(t);
+                load_frags(cur, 0, a0, b0);
+            }
+            mma(a0, b0);
         } else {
             for (int t = 0; t + 1 < ntiles; ++t) {
                 next_tile(t);
@@ -928,7 +937,7 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
 
     // ---- epilogue: lane owns m = .. + l15, n = .. + 4g + {0..3} ---------------------------------
     const unsigned epi = epi_flags(a);
-    const int split_k = a.split_k, argM = a.M, argN = a.N;
+    const int split_k = SK ? a.split_k : 1, argM = a.M, argN = a.N;
     float* splitk_ws = a.splitk_ws;
     if constexpr (ROWSUM) {
         if (do_rowsum && g == 0) {           // every n of the ones-operand holds the same sum: lanes 0..15 write one row each
@@ -1128,6 +1137,36 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
     HS_STAMP(4);
 }
 
+template <int BM, int BN, int BK, int AK, int BKIND, bool VEC, int WGM = 2, bool RS = false, int NS = 3>
+__global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) {
+    gemm_bf16_body<BM, BN, BK, AK, BKIND, VEC, WGM, RS, NS>(a, blockIdx.x, blockIdx.z);
+}
+// The 128x128 tile with BK = 32 takes 48 KB of LDS: three workgroups fit a CU if their registers do (<= 168 per lane).  A
+// 4096 x 3072 output is 768 tiles: one resident round on 256 CUs x 3 instead of one and a half on 256 x 2.
+#ifndef HS_W3_RING
+#define HS_W3_RING 3
+#endif
+template <int AK, int BKIND>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_bf16_kernel_w3(const GemmArgs a) {
+    gemm_bf16_body<128, 128, 32, AK, BKIND, true, 2, false, HS_W3_RING, false>(a, blockIdx.x, blockIdx.z);
+}
+
+// Grouped launch: the workgroups of up to 64 independent GEMMs of one operand layout (64x64 tiles) in ONE grid.  The weight
+// gradients of a ResNet backward are 53 such GEMMs with a long K and a small output: each alone is a short stream plus the
+// split-K hand-off tail on a mostly idle chip; together they fill it and there is one tail.  first_wg[i] = first workgroup
+// of problem i (ascending, first_wg[0] = 0, first_wg[n] = grid size); list[i] = its arguments, in device memory.
+template <int AK, int BKIND>
+__global__ __launch_bounds__(256) void gemm_bf16_grouped_kernel(const GemmArgs* __restrict__ list, const int* __restrict__ first_wg, int n) {
+    const int bid = blockIdx.x, lane = threadIdx.x & 63;
+    const int lo = lane < n ? first_wg[lane] : 0x7fffffff;
+    const int p = __builtin_amdgcn_readfirstlane(__popcll(__ballot(lo <= bid)) - 1);
+    const int local = bid - __builtin_amdgcn_readfirstlane(first_wg[p]);
+    const GemmArgs& a = list[p];
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int bz = local / tiles;
+    gemm_bf16_body<64, 64, 64, AK, BKIND, true>(a, local - bz * tiles, bz);
+}
+
 // ================================================================================================
 // exact-f32 kernel (v_mfma_f32_32x32x2_f32); BK = 32
 // ================================================================================================
@@ -1145,7 +1184,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hh = lane >> 5;
     int tm, tn;
-    tile_from_block(a, tm, tn);
+    tile_from_block(a, tm, tn, blockIdx.x);
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.z;
 

@@ -6,6 +6,9 @@ enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_STEM = 3, CFG_256x128
 // combos: 0 (KC,KC) 1 (KC,RC) 2 (RC,RC) 3 (CONV,KC) 4 (DGRAD,WDGRAD) 5 (RC,CONV)
 int launch_bf16_plain(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s);
 int launch_bf16_conv(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s);
+// one grid for n <= 64 problems of one operand layout, 64x64 tiles (gemm_bf16_grouped_kernel); tables in device memory
+int launch_bf16_grouped_plain(int combo, const GemmArgs* list, const int* first_wg, int n, int total_wgs, hipStream_t s);
+int launch_bf16_grouped_conv(int combo, const GemmArgs* list, const int* first_wg, int n, int total_wgs, hipStream_t s);
 int launch_f32_plain(int cfg, int combo, bool vec, const GemmArgs& a, dim3 grid, hipStream_t s);
 int launch_f32_conv(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s);
 

@@ -60,6 +60,11 @@ def main():
     shapes = [("nt", 4096, 2304, 768), ("nt", 4096, 768, 768), ("nt", 4096, 3072, 768), ("nt", 4096, 768, 3072),
               ("nn", 4096, 3072, 768), ("nn", 4096, 768, 3072), ("nn", 4096, 768, 2304), ("nn", 4096, 768, 768),
               ("tn", 3072, 768, 4096), ("tn", 768, 3072, 4096), ("tn", 2304, 768, 4096), ("tn", 768, 768, 4096)]
+    splits = (1, 2, 4, 8)
+    if "--resnet-wgrad" in sys.argv:      # 1x1 weight gradients of ResNet50 at batch 32: (Cout, Cin, N*H*W)
+        shapes = [("tn", 256, 64, 100352), ("tn", 64, 256, 100352), ("tn", 128, 256, 100352), ("tn", 512, 128, 25088),
+                  ("tn", 128, 512, 25088), ("tn", 1024, 256, 6272), ("tn", 256, 1024, 6272), ("tn", 2048, 512, 1568)]
+        splits = (1, 4, 8, 16, 32, 64, 128, 256)
     only = [a for a in sys.argv[1:] if a in ("nt", "nn", "tn")]
     for kind, M, N, K in shapes:
         if only and kind not in only:
@@ -69,8 +74,8 @@ def main():
         best = None
         cells = []
         for cfg, name in CFGS.items():
-            for split in (1, 2, 4, 8):
-                if K // split < 384:
+            for split in splits:
+                if K // split < 384 or (split > 8 and (M // 64) * (N // 64) * split > 4096):
                     continue
                 lib.hs_gemm_debug(cfg, 0)
                 try:

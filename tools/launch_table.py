@@ -4,7 +4,7 @@ import collections
 import csv
 import sys
 
-COMBO = ["nt", "nn", "tn", "conv", "dgrad", "wgrad"]
+COMBO = ["nt", "nn", "tn", "conv", "dgrad", "wgrad", "tn-grp", "wg-grp"]
 CFG = {0: "128x128", 1: "128x64", 2: "64x64", 3: "stem", 4: "256x128", 5: "128x128k32", 6: "256x128k32"}
 
 
@@ -22,6 +22,8 @@ def main(path, steps=2):
             nbytes = 2.0 * (M * N + N * K) + 2.0 * M * K / (R * R) / (stride * stride)
         elif combo == 5:
             nbytes = 2.0 * (M * K + N * K / (R * R) * stride * stride) + 4.0 * M * N
+        if len(r) > 12 and float(r[12]) > 0:
+            nbytes = float(r[12])            # grouped launch: bytes of all its problems (M = their number)
         a = agg.setdefault((combo, cfg, M, N, K, batch, split, R, stride), [0, 0.0, flop, nbytes])
         a[0] += 1
         a[1] += ms

@@ -1,6 +1,6 @@
-set -x
-python -m pytest tests/test_gemm_gpu.py tests/test_tower_gpu.py tests/test_product_gpu.py -q -x > gpurun_out/a_tests.log 2>&1; echo tests=$?; tail -3 gpurun_out/a_tests.log
-python bench.py --no-f32 --no-cpu-baseline --gemm-log gpurun_out/launches_a.csv > gpurun_out/a_bench.json 2> gpurun_out/a_bench.err; tail -2 gpurun_out/a_bench.err | cut -c1-300
-python tools/launch_table.py gpurun_out/launches_a.csv > gpurun_out/launch_table_a.txt
-HAMSPINE_SPLIT_UNITS=1024 HAMSPINE_SPLIT_MAX=128 python bench.py --no-f32 --no-cpu-baseline --gemm-log gpurun_out/launches_a2.csv > gpurun_out/a2_bench.json 2> gpurun_out/a2_bench.err; tail -2 gpurun_out/a2_bench.err | cut -c1-300
-python tools/launch_table.py gpurun_out/launches_a2.csv > gpurun_out/launch_table_a2.txt
+R=$(pwd); OUT=$R/gpurun_out/tl; rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace -d $OUT/ovl -o ovl -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32 > $OUT/ovl.log 2>&1
+cd $R
+grep "steps in" $OUT/ovl.log | cut -c1-200
+python3 tools/timeline.py $OUT/ovl/ovl_results.db 5 9 > gpurun_out/timeline.txt 2>&1
