@@ -6,7 +6,7 @@ import json
 import sqlite3
 import sys
 
-FAMILY = "gemm_bf16_kernel"
+FAMILY = "gemm_bf16_"        # gemm_bf16_kernel<...>, gemm_bf16_kernel_w3<...>, gemm_bf16_grouped_kernel<...>
 
 
 def per_family(path):
@@ -23,7 +23,7 @@ def main(fetch_db, write_db, out):
     fetch_b = 2.0 * f_kb * 1024.0
     write_b = w_kb * 1024.0
     res = {
-        "kernel_family": FAMILY, "launches": f_n,
+        "kernel_family": "gemm_bf16_kernel / _kernel_w3 / _grouped_kernel", "launches": f_n,
         "fetch_bytes_per_launch": fetch_b / f_n, "write_bytes_per_launch": write_b / f_n,
         "traffic_bytes_per_launch": (fetch_b + write_b) / f_n,
         "all_kernels_bytes_total": 2.0 * f_all * 1024.0 + w_all * 1024.0, "all_kernels_launches": n_all,

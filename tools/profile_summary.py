@@ -2,12 +2,13 @@
 <out>_kernel_stats.csv (Name, Calls, TotalDurationNs, AverageNs, Percentage) and <out>_summary.md.
 
 usage: profile_summary.py results.db steps_in_trace out_prefix "title line" ["extra paragraph"]
-steps_in_trace = warm-up + timed + the 3 steps of bench.py's roofline leg."""
+steps_in_trace = every step bench.py ran (warm-up, timed, the single-step host probes, the roofline leg); 0 = count the
+image tower's pack_image_kernel launches (one per step of C2 / C3)."""
 import collections
 import sqlite3
 import sys
 
-FAMILY = "gemm_bf16_kernel"
+FAMILY = "gemm_bf16_"        # gemm_bf16_kernel<...>, gemm_bf16_kernel_w3<...>, gemm_bf16_grouped_kernel<...>
 TFLOP_PER_STEP = 2.897       # bench.py: algorithmic_tflop_per_step of the family (strided dgrads count executed taps)
 PEAK = 2500.0
 
@@ -20,6 +21,8 @@ def main(db_path, steps, out, title, extra=""):
         e = by.setdefault(name, [0, 0])
         e[0] += 1
         e[1] += d
+    if steps <= 0:
+        steps = sum(c for n, (c, t) in by.items() if "pack_image" in n)
     total = sum(v[1] for v in by.values())
     order = sorted(by.items(), key=lambda kv: -kv[1][1])
     with open(out + "_kernel_stats.csv", "w") as f:
@@ -36,7 +39,7 @@ def main(db_path, steps, out, title, extra=""):
             f.write(extra.strip() + "\n\n")
         f.write(f"* steps in the trace: {steps}; kernel time per step (sum of durations): **{total / steps / 1e6:.2f} ms**, "
                 f"{len(rows) / steps:.0f} launches/step\n")
-        f.write(f"* dominant kernel family `{FAMILY}<...>`: **{ms:.2f} ms/step**, {fam_c / steps:.0f} launches/step, "
+        f.write(f"* dominant kernel family `gemm_bf16_kernel<...>` (+ `_w3`, `_grouped`): **{ms:.2f} ms/step**, {fam_c / steps:.0f} launches/step, "
                 f"average launch {fam_t / fam_c / 1e3:.1f} us -> {TFLOP_PER_STEP:.2f} TFLOP / {ms:.2f} ms = **{tf:.0f} TFLOP/s** "
                 f"({100.0 * tf / PEAK:.1f} % of the 2.5 PFLOP/s dense bf16 MFMA peak)\n\n")
         f.write("| ms/step | % | calls/step | avg us | kernel |\n|---|---|---|---|---|\n")

@@ -1,6 +1,3 @@
-R=$(pwd); OUT=$R/gpurun_out/tl; rm -rf $OUT; mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace -d $OUT/ovl -o ovl -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32 > $OUT/ovl.log 2>&1
-cd $R
-grep "steps in" $OUT/ovl.log | cut -c1-200
-python3 tools/timeline.py $OUT/ovl/ovl_results.db 5 9 > gpurun_out/timeline.txt 2>&1
+python -m pytest tests -q -m gpu > gpurun_out/r2_gpu_suite.log 2>&1; echo suite=$?; tail -4 gpurun_out/r2_gpu_suite.log
+python bench.py > gpurun_out/r2_bench_c2.json 2> gpurun_out/r2_bench_c2.err; grep "steps in" gpurun_out/r2_bench_c2.err | cut -c1-200
+HAMSPINE_TOWER_OVERLAP=0 python bench.py --no-f32 --no-cpu-baseline > gpurun_out/r2_bench_c2_serial.json 2> gpurun_out/r2_bench_c2_serial.err; grep "steps in" gpurun_out/r2_bench_c2_serial.err | cut -c1-200
