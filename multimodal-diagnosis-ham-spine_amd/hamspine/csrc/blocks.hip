@@ -152,6 +152,18 @@ static void run_init(Run& r, int dt, bool plan, void* saved, long long saved_byt
     do {                                     \
         if (!(r).plan) HS_PROPAGATE(expr);   \
     } while (0)
+// Measurement only (HAMSPINE_KNOCKOUT=<bit mask>, off by default): leave a class of launches OUT of the step to read its
+// marginal cost in the overlapped schedule off the step time (results are then garbage; tools/knockout.sh).  Bits: 1 ResNet
+// weight gradients, 2 BERT weight-gradient GEMMs, 4 transposes, 8 BatchNorm forward, 16 BatchNorm backward, 64 weight casts,
+// 128 LayerNorm backward, 256 attention cores, 512 ResNet data-gradient convolutions, 1024 BERT data-gradient GEMMs.
+static int knock() {
+    static const int v = [] { const char* e = getenv("HAMSPINE_KNOCKOUT"); return e ? atoi(e) : 0; }();
+    return v;
+}
+#define CALLK(r, bit, expr)                                        \
+    do {                                                           \
+        if (!(r).plan && !(knock() & (bit))) HS_PROPAGATE(expr);   \
+    } while (0)
 
 static hs_gemm_params gemm_defaults(int dt) {
     hs_gemm_params p;
@@ -175,7 +187,8 @@ static int gemm_splitk(Run& r, hs_gemm_params& p, bool may_defer = false) {
             set_error("gemm_splitk: workspace too small");
             return HS_ERR_ARG;
         }
-        if (defer) HS_PROPAGATE(gemm_group_add(p.b_kind == HS_B_CONV ? r.grp_conv : r.grp_pw, &p, r.s));
+        if (may_defer && (knock() & 1)) {
+        } else if (defer) HS_PROPAGATE(gemm_group_add(p.b_kind == HS_B_CONV ? r.grp_conv : r.grp_pw, &p, r.s));
         else HS_PROPAGATE(gemm_impl(&p, r.s));
     }
     if (defer) return HS_OK;                 // the slabs stay allocated until the grouped launch has run
@@ -216,6 +229,7 @@ static int attention_fwd_run(Run& r, const hs_attn_desc& d, const void* q, const
     HS_PROPAGATE(attn_check(d));
     AttnLayout l = attn_layout(d, r, false);
     const int BH = d.B * d.H;
+    if (!r.plan && (knock() & 256)) return HS_OK;
     if (!r.plan && !r.saved.overflow && !r.ws.overflow) {
         // BERT shape (bf16, head dim 64, <= 128 tokens): one fused kernel, scores stay in registers (csrc/attn_fused.hip)
         const int fused = attention_fwd_fused(d, q, k, v, o, l.P, l.Pd, l.ldP, r.s);
@@ -270,6 +284,7 @@ static int attention_bwd_run(Run& r, const hs_attn_desc& d, const void* q, const
     const int BH = d.B * d.H;
     const long long o_el = span_elems(d.B, d.o_bs, d.Lq, d.o_ld, d.H, d.hd);
     const long long p_el = (long long)BH * d.Lq * l.ldP;
+    if (!r.plan && (knock() & 256)) return HS_OK;
     if (!r.plan && !r.saved.overflow && !r.ws.overflow) {
         // BERT shape: one fused kernel (csrc/attn_fused.hip) instead of four batched GEMMs and the softmax backward
         const int fused = attention_bwd_fused(d, q, k, v, dO, dq, dk, dv, l.P, l.ldP, r.s);
@@ -417,7 +432,7 @@ static bool wgrad_nt_enabled() {             // off: weight gradients from the r
     return g_wgrad_nt == 1;
 }
 static int transpose_run(Run& r, const void* src, void* dst, long long R, int Cc, int ld_src) {
-    CALL(r, hs_transpose_bf16(src, dst, (int)R, Cc, ld_src, R, r.s));
+    CALLK(r, 4, hs_transpose_bf16(src, dst, (int)R, Cc, ld_src, R, r.s));
     return HS_OK;
 }
 // seg: 0 = plain; 3 = fused Q/K/V (lin = the q layer; D_seg / rowsum_seg = k, v)
@@ -443,6 +458,7 @@ static int linear_wgrad_nt_run(Run& r, const void* xT, const void* dyT, long lon
             p.rowsum_seg[1] = db_seg[1];
         }
     }
+    if (!r.plan && (knock() & 2)) { const int sp = hs_gemm_suggest_split(p.M, p.N, p.K, p.dtype); p.split_k = sp; if (sp > 1) (void)r.ws.alloc(hs_gemm_splitk_ws_bytes(&p)); return HS_OK; }
     return gemm_splitk(r, p);
 }
 // dx = dy W (* multiplier) (+ residual)
@@ -458,7 +474,7 @@ static int linear_dgrad_run(Run& r, const hs_linear& lin, const void* w_c, const
     p.D = dx; p.ldd = lddx; p.out_dtype = dx_dtype;
     p.mul_mode = mul_mode; p.mul_src = mul_src; p.ldm = ldm;
     p.residual = residual; p.ldr = lddx;
-    CALL(r, gemm_impl(&p, r.s));
+    CALLK(r, 1024, gemm_impl(&p, r.s));
     return HS_OK;
 }
 
@@ -570,6 +586,7 @@ static int conv_dgrad_run(Run& r, const ConvShape& s, const void* dy, const void
     }
     // late layers: few output tiles under a long K (7x7 maps: 200 tiles x 72 K tiles) -- split-K, reduced inside the launch
     // with the full epilogue (the parity-ordered stride-2 walk has its own K schedule and stays whole)
+    if (!r.plan && (knock() & 512)) return HS_OK;
     if (r.dt == HS_BF16 && s.stride == 1) return gemm_splitk(r, p);
     CALL(r, gemm_impl(&p, r.s));
     return HS_OK;
@@ -609,6 +626,7 @@ static const void* weight_c(Run& r, CastList& cl, const float* w, long long n) {
 }
 static int run_casts(Run& r, CastList& cl) {
     if (cl.count == 0 || r.plan) return HS_OK;
+    if (knock() & 64) return HS_OK;
     return hs_cast_f32_to_bf16_multi(cl.count, cl.src, cl.dst, cl.n, r.s);
 }
 
@@ -690,7 +708,7 @@ static int resblock_fwd_run(Run& r, const hs_resblock_desc& d, const void* x, vo
             hs_bn_params bp = bn_params(r, d, cb, b, Mo);
             bp.y = nullptr;                                   // statistics only: fills b.scale / b.shift
             bp.ws = L.bn_ws; bp.ws_bytes = L.bn_ws_bytes;
-            CALL(r, hs_batchnorm_fwd(&bp, r.s));
+            CALLK(r, 8, hs_batchnorm_fwd(&bp, r.s));
             FoldedBn f;
             f.scale = b.scale; f.shift = b.shift; f.relu = relu; f.identity = ident;
             return conv_fwd_run(r, b.s, in, b.w_c, out, nullptr, nullptr, &f);
@@ -714,7 +732,7 @@ static int resblock_fwd_run(Run& r, const hs_resblock_desc& d, const void* x, vo
         hs_bn_params bp = bn_params(r, d, d.ds, L.ds, Mo);
         bp.y = L.ds.a; bp.relu = 0;
         bp.ws = L.bn_ws; bp.ws_bytes = L.bn_ws_bytes; bp.partial_rows = srows;
-        CALL(r, hs_batchnorm_fwd(&bp, r.s));
+        CALLK(r, 8, hs_batchnorm_fwd(&bp, r.s));
         identity = L.ds.a;
     }
     const void* in = x;
@@ -729,7 +747,7 @@ static int resblock_fwd_run(Run& r, const hs_resblock_desc& d, const void* x, vo
         bp.relu = 1;
         bp.residual = last ? identity : nullptr;
         bp.ws = L.bn_ws; bp.ws_bytes = L.bn_ws_bytes; bp.partial_rows = srows;
-        CALL(r, hs_batchnorm_fwd(&bp, r.s));
+        CALLK(r, 8, hs_batchnorm_fwd(&bp, r.s));
         in = b.a;
     }
     return HS_OK;
@@ -779,7 +797,7 @@ static int resblock_bwd_run(Run& r, const hs_resblock_desc& d, const void* x, co
         q.dgamma = cb.dgamma ? cb.dgamma : scratch_pg;
         q.dbeta = cb.dbeta ? cb.dbeta : (scratch_pg ? scratch_pg + 4096 : nullptr);
         q.ws = L.bn_ws; q.ws_bytes = L.bn_ws_bytes;
-        CALL(r, hs_batchnorm_bwd(&q, r.s));
+        CALLK(r, 16, hs_batchnorm_bwd(&q, r.s));
         return HS_OK;
     };
 
@@ -886,7 +904,7 @@ static int stem_fwd_run(Run& r, const hs_stem_desc& d, const float* image, void*
         be.gamma = cb.gamma; be.beta = cb.beta; be.running_mean = cb.running_mean; be.running_var = cb.running_var;
         be.save_mean = L.mean; be.save_invstd = L.invstd; be.scale = L.scale; be.shift = L.shift;
         be.ws = L.bn_ws; be.ws_bytes = L.bn_ws_bytes;
-        CALL(r, hs_batchnorm_fwd(&be, r.s));
+        CALLK(r, 8, hs_batchnorm_fwd(&be, r.s));
         p.colscale = L.scale; p.bias = L.shift; p.act = HS_ACT_RELU;
         p.D = L.a;                                            // BatchNorm + ReLU folded: the GEMM writes the pooled input
         CALL(r, gemm_impl(&p, r.s));
@@ -907,7 +925,7 @@ static int stem_fwd_run(Run& r, const hs_stem_desc& d, const float* image, void*
     bp.running_mean = cb.running_mean; bp.running_var = cb.running_var;
     bp.save_mean = L.mean; bp.save_invstd = L.invstd; bp.scale = L.scale; bp.shift = L.shift;
     bp.ws = L.bn_ws; bp.ws_bytes = L.bn_ws_bytes;
-    CALL(r, hs_batchnorm_fwd(&bp, r.s));
+    CALLK(r, 8, hs_batchnorm_fwd(&bp, r.s));
     CALL(r, hs_maxpool_fwd(r.dt, L.a, y, L.idx, d.N, L.P, L.Q, cb.Cout, 3, 2, 1, r.s));
     return HS_OK;
 }
@@ -934,7 +952,7 @@ static int stem_bwd_run(Run& r, const hs_stem_desc& d, const void* y, const void
     q.dgamma = cb.dgamma ? cb.dgamma : scratch_pg;
     q.dbeta = cb.dbeta ? cb.dbeta : (scratch_pg ? scratch_pg + 64 : nullptr);
     q.ws = L.bn_ws; q.ws_bytes = L.bn_ws_bytes;
-    CALL(r, hs_batchnorm_bwd(&q, r.s));
+    CALLK(r, 16, hs_batchnorm_bwd(&q, r.s));
     if (cb.dw) {
         hs_gemm_params p = gemm_defaults(r.dt);
         p.a_kind = HS_A_RC; p.b_kind = HS_B_CONV;
@@ -1089,7 +1107,7 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
                                      ln_ws, ln_ws_bytes, M, Hd, r.s));
         out_l_w.db = nullptr;                  // bias gradient already produced above
     } else {
-        CALL(r, hs_layernorm_bwd(r.dt, dy, L.h2, d.ln2.gamma, L.mean2, L.rstd2, dh2, d.ln2.dgamma ? d.ln2.dgamma : scratch,
+        CALLK(r, 128, hs_layernorm_bwd(r.dt, dy, L.h2, d.ln2.gamma, L.mean2, L.rstd2, dh2, d.ln2.dgamma ? d.ln2.dgamma : scratch,
                                  d.ln2.dbeta ? d.ln2.dbeta : (scratch ? scratch + Hd : nullptr), ln_ws, ln_ws_bytes, M, Hd, r.s));
         if (d.hidden_dropout > 0.f) CALL(r, hs_dropout(r.dt, dh2, dd2, M * Hd, d.hidden_dropout, d.seed * 8 + 3, r.s));
     }
@@ -1127,7 +1145,7 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
                                      ln_ws, ln_ws_bytes, M, Hd, r.s));
         ao_w.db = nullptr;
     } else {
-        CALL(r, hs_layernorm_bwd(r.dt, dx1, L.h1, d.ln1.gamma, L.mean1, L.rstd1, dh1, d.ln1.dgamma ? d.ln1.dgamma : scratch,
+        CALLK(r, 128, hs_layernorm_bwd(r.dt, dx1, L.h1, d.ln1.gamma, L.mean1, L.rstd1, dh1, d.ln1.dgamma ? d.ln1.dgamma : scratch,
                                  d.ln1.dbeta ? d.ln1.dbeta : (scratch ? scratch + Hd : nullptr), ln_ws, ln_ws_bytes, M, Hd, r.s));
         if (d.hidden_dropout > 0.f) CALL(r, hs_dropout(r.dt, dh1, dd1, M * Hd, d.hidden_dropout, d.seed * 8 + 2, r.s));
     }
@@ -1400,7 +1418,7 @@ static int bert_bwd_run(Run& r, const hs_bert_desc& d, const int64_t* ids, const
     void* csws = r.ws.alloc(csb);
     float* scratch = (float*)r.ws.alloc(2ll * Hd * 4);
     const float* stats = base ? (const float*)(base + lo.stats_off) : nullptr;
-    CALL(r, hs_layernorm_bwd(d.dtype, g, base ? base + lo.ssum_off : nullptr, d.gamma, stats, stats ? stats + M : nullptr, dsum,
+    CALLK(r, 128, hs_layernorm_bwd(d.dtype, g, base ? base + lo.ssum_off : nullptr, d.gamma, stats, stats ? stats + M : nullptr, dsum,
                              d.dgamma ? d.dgamma : scratch, d.dbeta ? d.dbeta : (scratch ? scratch + Hd : nullptr), lnws, lnb, M,
                              Hd, r.s));
     if (!r.plan) {

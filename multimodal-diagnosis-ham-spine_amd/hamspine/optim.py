@@ -12,6 +12,10 @@ from . import _lib as L
 from . import rt
 
 
+import os as _os
+_KNOCK_ADAM = int(_os.environ.get("HAMSPINE_KNOCKOUT", "0")) & 32 != 0     # measurement only: see csrc/blocks.hip knock()
+
+
 class _FusedAdamBase(torch.optim.Optimizer):
     _decoupled = True
 
@@ -109,7 +113,7 @@ class _FusedAdamBase(torch.optim.Optimizer):
         per-tensor checks -- is built once per parameter set, the step counter is ONE shared 0-dim tensor per chunk
         (state[p]["step"] of every tensor in it), and the gradient pointer table is rebuilt only when a gradient pointer
         changed (the tower executors and hamspine.ddp hand out the same gradient memory every step)."""
-        if not ps:
+        if not ps or _KNOCK_ADAM:
             return
         lib = L.lib()
         key = (id(group), len(ps), id(ps[0]), id(ps[-1]))
