@@ -377,6 +377,25 @@ static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q
         }
     }
     dim3 grid(a.tiles_m * a.tiles_n, 1, split > 1 ? split : batch);
+    {   // persistent launch: more tiles than workgroups the chip holds at once -> one workgroup per resident slot walks
+        // several tiles and prefetches the next tile under the current epilogue.  Built, parity-tested and measured: no gain
+        // (4096x3072x768 as 128x64 tiles 40.1 vs 39.8 us; the K = 64 ResNet layers 36.0 vs 31.2 us, because the variant's
+        // registers leave room for 2 instead of 3-5 workgroups per CU and those layers live on bytes in flight): the
+        // hardware already overlaps one workgroup's set-up with its neighbours' epilogues.  OFF unless HAMSPINE_PERSISTENT=1
+        // (or hs_gemm_debug ablation bit 64).
+        static const bool on = [] { const char* e = getenv("HAMSPINE_PERSISTENT"); return e && e[0] == '1'; }();
+        static const int cus = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+        if ((on || (g_dbg_ablate & 64)) && bf16 && split == 1 && batch == 1 && !a.stamps && !p->rowsum_a && (cfg == CFG_64x64 || cfg == CFG_128x64) &&
+            (combo == 0 || combo == 1 || combo == 3 || combo == 4)) {
+            const int lds = a.lds_stages * (BM + BN) * 64 * 2;
+            const int per_cu = std::max(1, std::min(cfg == CFG_64x64 ? 3 : 2, (160 * 1024) / lds));   // 168 / 256 VGPRs, LDS
+            const int slots = cus * per_cu;
+            if ((int)grid.x > slots) {
+                a.persist = slots;
+                grid.x = slots;
+            }
+        }
+    }
     double flops = 2.0 * p->M * p->N * (double)p->K * batch;
     if (a.parity) {   // strided dgrad: only the (pixel parity, filter tap) pairs that reach an output pixel are real work
         int kept = 0;

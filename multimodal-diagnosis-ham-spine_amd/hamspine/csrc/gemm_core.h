@@ -41,6 +41,7 @@ struct GemmArgs {
     const float* colscale;     // optional per-column scale before the bias (folded eval-mode BatchNorm)
     int res_pre_act;           // residual is added before the activation
     float* colstats;           // optional per (row tile, column) (count, mean, M2) of the result (fused BatchNorm statistics)
+    int persist;               // >0: persistent launch, grid size = tile stride (split_k == 1, batch == 1)
     int lds_stages;            // ring slots actually allocated: min(3, K tiles per workgroup) (bf16 kernel)
     int split_k;               // >1: blockIdx.z is the split index
     int k_per_split;           // multiple of BK
@@ -600,7 +601,8 @@ __device__ __forceinline__ void wait_vm_tiles(int tiles) {       // wait until a
     }
 }
 // SK: the launch may be a split-K one (false: the slab / hand-off code is left out -- its registers count against every launch).
-template <int BM, int BN, int BK, int AK, int BKIND, bool VEC, int WGM = 2, bool RS = false, int NS = 3, bool SK = true>
+// PS: persistent-capable (the tile loop and the next-tile prefetch are compiled in; costs registers, so it is a variant).
+template <int BM, int BN, int BK, int AK, int BKIND, bool VEC, int WGM = 2, bool RS = false, int NS = 3, bool SK = true, bool PS = false>
 __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, const int bz) {
     typedef bf16_t T;
     constexpr int ESZ = 2;
@@ -631,8 +633,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
         asm volatile("" ::"s"(q0), "s"(q1), "s"(q2), "s"(q3), "s"(q4), "s"(q5), "s"(q6), "s"(q7), "s"(q8), "s"(q9), "s"(q10),
                      "s"(pa), "s"(pb), "s"(ba), "s"(bb));
     }
-    tile_from_block(a, tm, tn, bx);
-    const int m0 = tm * BM, n0 = tn * BN;
+    int m0, n0;
     const int z = bz;
 
     long long a_boff = 0, b_boff = 0, d_boff = 0;
@@ -658,6 +659,22 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
     KcRow<HS_A_KC> b_rows[B_RC ? 1 : B_NI];
     RcCol a_cols[A_RC ? A_NI : 1], b_cols[B_RC ? B_NI : 1];
     int a_kl[A_NI], b_kl[B_NI];   // KC: logical k-chunk (x8) of the slot; RC: local k row of the slot
+    constexpr int NDMA = A_NI + B_NI;
+    static_assert(NS >= 3 && NS <= 8 && (NS - 1) * NDMA <= 63, "ring depth: the vmcnt field holds 6 bits");
+    constexpr int KS = BK / 32;
+    int ntiles = 0;
+    // stride-2 dgrad with parity-major rows: when every row of this tile is in one parity class, only the filter taps
+    // (r, s) with (class_h + pad - r) and (class_w + pad - s) even can reach a stored output pixel; the K walk keeps just
+    // those taps (1, 2, 2 or 4 of 9 for a 3x3 filter; 1 or 0 of 1 for a 1x1).  taps: 4 bits per kept tap index.
+    unsigned long long taps = 0;
+    int tiles_per_tap = 1;
+    bool filtered = false;
+    // everything that depends on WHICH output tile this workgroup works on (vb = the tile's position in launch order): a
+    // persistent launch (a.persist) calls it once per tile
+    auto setup_tile = [&](const int vb) {
+    tile_from_block(a, tm, tn, vb);
+    m0 = tm * BM;
+    n0 = tn * BN;
 #pragma unroll
     for (int i = 0; i < A_NI; ++i) {
         const int s = (wave * A_NI + i) * 64 + lane;
@@ -689,6 +706,29 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
             rc_col_setup<BKIND, false>(a, n0 + rc_logical_chunk<BN>(k, s % (BN / 8)) * 8, b_cols[i]);
         }
     }
+    ntiles = (kend - kbeg + BK - 1) / BK;
+    taps = 0;
+    tiles_per_tap = 1;
+    filtered = false;
+    if constexpr (AK == HS_A_DGRAD) {
+        if (a.parity) {
+            const int c_first = parity_class(a, m0), c_last = parity_class(a, min(m0 + BM, a.M) - 1);
+            if (c_first == c_last) {
+                filtered = true;
+                tiles_per_tap = a.g.K / BK;
+                int kept = 0;
+                for (int r = 0; r < a.g.R; ++r)
+                    for (int q = 0; q < a.g.S; ++q)
+                        if ((((c_first >> 1) + a.g.pad - r) & 1) == 0 && (((c_first & 1) + a.g.pad - q) & 1) == 0) {
+                            taps |= (unsigned long long)(r * a.g.S + q) << (4 * kept);
+                            ++kept;
+                        }
+                ntiles = kept * tiles_per_tap;
+            }
+        }
+    }
+    };   // setup_tile
+    setup_tile(bx);
 
     auto stage_dma = [&](int buf, int k0) {
         KTile kta = {0, 0, 0}, ktb = {0, 0, 0};
@@ -714,19 +754,10 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
     };
 
     f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // bias gradient of a weight-gradient GEMM (A = dY stored [k][m]): the column sums of dY are one more output column,
     // dY^T . 1 -- the waves of the first tile column feed their A fragments to one extra MFMA against a fragment of ones.
     f32x4 accb[ROWSUM ? FM : 1];
     bool do_rowsum = false;
-    if constexpr (ROWSUM) {
-        do_rowsum = a.rowsum[0] != nullptr && tn == 0 && wn == 0;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
 
     // 3-slot LDS ring, software pipelined at two levels.
     //  * tiles: when the waves meet at the barrier of tile t, tile t+1 has landed, tile t+2 is in flight and the
@@ -736,33 +767,6 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
     //  * fragments: the ds_reads of k-phase p+1 (or of phase 0 of the next tile, right after the barrier) are issued
     //    before the MFMAs of phase p, into the other half of a double-buffered fragment set, so the LDS latency
     //    hides under 8..16 MFMAs instead of stalling every MFMA pair.
-    constexpr int NDMA = A_NI + B_NI;
-    static_assert(NS >= 3 && NS <= 8 && (NS - 1) * NDMA <= 63, "ring depth: the vmcnt field holds 6 bits");
-    constexpr int KS = BK / 32;
-    int ntiles = (kend - kbeg + BK - 1) / BK;
-    // stride-2 dgrad with parity-major rows: when every row of this tile is in one parity class, only the filter taps
-    // (r, s) with (class_h + pad - r) and (class_w + pad - s) even can reach a stored output pixel; the K walk keeps just
-    // those taps (1, 2, 2 or 4 of 9 for a 3x3 filter; 1 or 0 of 1 for a 1x1).  taps: 4 bits per kept tap index.
-    unsigned long long taps = 0;
-    int tiles_per_tap = 1;
-    bool filtered = false;
-    if constexpr (AK == HS_A_DGRAD) {
-        if (a.parity) {
-            const int c_first = parity_class(a, m0), c_last = parity_class(a, min(m0 + BM, a.M) - 1);
-            if (c_first == c_last) {
-                filtered = true;
-                tiles_per_tap = a.g.K / BK;
-                int kept = 0;
-                for (int r = 0; r < a.g.R; ++r)
-                    for (int q = 0; q < a.g.S; ++q)
-                        if ((((c_first >> 1) + a.g.pad - r) & 1) == 0 && (((c_first & 1) + a.g.pad - q) & 1) == 0) {
-                            taps |= (unsigned long long)(r * a.g.S + q) << (4 * kept);
-                            ++kept;
-                        }
-                ntiles = kept * tiles_per_tap;
-            }
-        }
-    }
     auto k_of = [&](int t) -> int {          // first k of the t-th tile of this workgroup's K walk
         if constexpr (AK == HS_A_DGRAD) {
             if (filtered) {
@@ -834,14 +838,41 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
         cur = cur == NS - 1 ? 0 : cur + 1;
     };
 
-    if (ntiles > 0) {
-        stage_dma(0, k_of(0));
-        HS_STAMP(1);
-        if (a.stamps && threadIdx.x == 0) a.stamps[((long long)blockIdx.z * gridDim.x + blockIdx.x) * 6] = t_entry;
+    // the first ring slots of the current tile's K walk
+    auto issue_prologue = [&]() {
+        if (ntiles > 0) {
+            stage_dma(0, k_of(0));
 #pragma unroll
-        for (int q = 1; q < NS; ++q)
-            if (q < ntiles) stage_dma(q, k_of(q));
-        wait_vm_tiles<NDMA>(min(NS, ntiles) - 1);
+            for (int q = 1; q < NS; ++q)
+                if (q < ntiles) stage_dma(q, k_of(q));
+        }
+    };
+    issue_prologue();
+    HS_STAMP(1);
+    if (a.stamps && threadIdx.x == 0) a.stamps[((long long)blockIdx.z * gridDim.x + blockIdx.x) * 6] = t_entry;
+    // Persistent launches (a.persist = grid size > 0; plain bf16 GEMMs / convolutions with more tiles than the chip holds at
+    // once): the workgroup walks tiles vb, vb + grid, ... and issues the NEXT tile's address set-up and first ring slots
+    // before the CURRENT tile's epilogue, so the ~1.9 us from tile entry to the first landed operands (tools/gemm_stamps.py)
+    // run under the epilogue's stores instead of in front of every K loop.
+    const int pstride = PS ? a.persist : 0;
+    int vb = bx;
+    bool first_tile = true;
+    for (;;) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (ROWSUM) {
+        do_rowsum = a.rowsum[0] != nullptr && tn == 0 && wn == 0;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    cur = 0;
+    if (ntiles > 0) {
+        // first tile: counted wait (all but the newest in-flight slots); later tiles: the epilogue's loads and stores sit
+        // between this K walk's DMAs in the memory pipe, so drain everything (the slots have had the whole epilogue to land)
+        if (first_tile) wait_vm_tiles<NDMA>(min(NS, ntiles) - 1);
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         HS_STAMP(2);
         bf16x8 a0[FM], b0[FN], a1[FM], b1[FN];
@@ -1104,14 +1135,24 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
             ticket = a.tickets + tile_id;
         }
     }
+    // ---- next tile's set-up and first operand slots go out before this tile's epilogue (persistent launches) ----------
+    const int em0 = m0, en0 = n0;
+    const int nvb = vb + pstride;
+    const bool more = PS && pstride > 0 && nvb < a.tiles_m * a.tiles_n;
+    if (more) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every wave is done reading this tile's last fragments
+        __builtin_amdgcn_s_barrier();
+        setup_tile(nvb);
+        issue_prologue();
+    }
     // whole tile inside the matrix and 4-wide storable: one of the feature sets the training / inference steps use gets
     // branch-free code; anything else (edge tiles, rare combinations) takes the generic body
-    const bool full = !a.epi_generic && (epi & EPI_VEC) && m0 + BM <= argM && n0 + BN <= argN;
+    const bool full = !a.epi_generic && (epi & EPI_VEC) && em0 + BM <= argM && en0 + BN <= argN;
     bool done = false;
     const int ze = split_k > 1 ? 0 : z;                       // batch index seen by the epilogue (a split-K launch has no batch)
     if (full) {
         done = true;
-#define HS_EPI_CASE(F) case (F): run_epilogue<T, (F), true, FM, FN, WM, WN>(a, epi, acc, m0, n0, wm, wn, l15, g, d_boff, ze); break
+#define HS_EPI_CASE(F) case (F): run_epilogue<T, (F), true, FM, FN, WM, WN>(a, epi, acc, em0, en0, wm, wn, l15, g, d_boff, ze); break
         const bool v16 = epi & EPI_VEC16;
         const unsigned key = epi & ~EPI_VEC16;
         if (!v16 && !(key & EPI_OUT_F32)) done = false;      // bf16 rows that cannot take 16-byte stores: generic body
@@ -1133,13 +1174,23 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
         }
 #undef HS_EPI_CASE
     }
-    if (!done) run_epilogue<T, -1, false, FM, FN, WM, WN>(a, epi, acc, m0, n0, wm, wn, l15, g, d_boff, ze);
+    if (!done) run_epilogue<T, -1, false, FM, FN, WM, WN>(a, epi, acc, em0, en0, wm, wn, l15, g, d_boff, ze);
     HS_STAMP(4);
+    if (!more) break;
+    vb = nvb;
+    first_tile = false;
+    }   // tiles of this workgroup
 }
 
 template <int BM, int BN, int BK, int AK, int BKIND, bool VEC, int WGM = 2, bool RS = false, int NS = 3>
 __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) {
     gemm_bf16_body<BM, BN, BK, AK, BKIND, VEC, WGM, RS, NS>(a, blockIdx.x, blockIdx.z);
+}
+// persistent-capable variant (64x64 and 128x64 tiles): launched with a.persist = grid size when a GEMM has more tiles than
+// the chip holds at once
+template <int BM, int BN, int AK, int BKIND>
+__global__ __launch_bounds__(256) void gemm_bf16_persistent_kernel(const GemmArgs a) {
+    gemm_bf16_body<BM, BN, 64, AK, BKIND, true, 2, false, 3, false, true>(a, blockIdx.x, 0);
 }
 // The 128x128 tile with BK = 32 takes 48 KB of LDS: three workgroups fit a CU if their registers do (<= 168 per lane).  A
 // 4096 x 3072 output is 768 tiles: one resident round on 256 CUs x 3 instead of one and a half on 256 x 2.

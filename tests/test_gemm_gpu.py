@@ -279,3 +279,45 @@ def test_splitk_in_launch_reduction(kind, M, N, K, split):
             raw.gemm(Ad, Bd, Db, M, N, K, bias=bd, split_k=split, **kw)
     torch.cuda.synchronize()
     assert torch.equal(Da.cpu(), outs[0]) and torch.equal(Db.cpu(), outs[0])
+
+
+@pytest.mark.parametrize("kind,M,N,K", [("nt", 100352, 64, 64), ("nt", 16384, 512, 256), ("nn", 12800, 320, 192), ("nt", 4096, 3072, 768),
+                                        ("nn", 100352, 256, 64)])
+def test_persistent_launch_equals_one_tile_per_workgroup(kind, M, N, K):
+    """The persistent variant of the GEMM kernel (a workgroup walks several tiles and prefetches the next tile's operands
+    under the current epilogue; off by default -- measured neutral to slower -- on with HAMSPINE_PERSISTENT=1 or hs_gemm_debug
+    ablation bit 64) is bit-identical to one workgroup per tile, with bias + GELU + pre-activation copy and with a residual,
+    on ragged tile counts."""
+    import ctypes as C
+    lib = L.lib()
+    lib.hs_gemm_debug.argtypes = [C.c_int32, C.c_int32]
+    g = torch.Generator().manual_seed(M + N)
+    BF = torch.bfloat16
+    A = torch.randn(M, K, generator=g).to(BF).to(DEV)
+    if kind == "nt":
+        B = torch.randn(N, K, generator=g).to(BF).to(DEV)
+        kw = dict(a_kind=L.A_KC, b_kind=L.B_KC, lda=K, ldb=K)
+        ref = A.float() @ B.float().T
+    else:
+        B = torch.randn(K, N, generator=g).to(BF).to(DEV)
+        kw = dict(a_kind=L.A_KC, b_kind=L.B_RC, lda=K, ldb=N)
+        ref = A.float() @ B.float()
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(M, N, generator=g).to(BF).to(DEV)
+    outs = []
+    for ablate in (0, 64):
+        lib.hs_gemm_debug(-1, ablate)
+        try:
+            D1 = torch.full((M, N), float("nan"), dtype=BF, device=DEV)
+            P1 = torch.full((M, N), float("nan"), dtype=BF, device=DEV)
+            raw.gemm(A, B, D1, M, N, K, bias=bias, act=L.ACT_GELU, preact=P1, **kw)
+            D2 = torch.full((M, N), float("nan"), dtype=BF, device=DEV)
+            raw.gemm(A, B, D2, M, N, K, residual=res, **kw)
+            D3 = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+            raw.gemm(A, B, D3, M, N, K, **kw)
+        finally:
+            lib.hs_gemm_debug(-1, 0)
+        outs.append((D1.cpu(), P1.cpu(), D2.cpu(), D3.cpu()))
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+    assert (outs[0][3] - ref.cpu()).abs().max().item() <= 2e-5 * K * 16
