@@ -1,6 +1,7 @@
 """KANLinear / KAN1 (reference ConNexT/models/block/kan1.py) with the same parameters (base_weight, spline_weight,
 spline_scaler), buffer (grid) and initialisation; the forward/backward run on the hamspine kernels in f32."""
 import math
+import types
 
 import torch
 
@@ -75,8 +76,34 @@ class KANLinear(torch.nn.Module):
                            self._base_act)
         return out.reshape(*shape[:-1], self.out_features)
 
+    @torch.no_grad()
     def update_grid(self, x, margin=0.01):
-        raise NotImplementedError("update_grid (data-dependent re-gridding, kan1.py:167-212) is not part of the per-batch path")
+        """Data-dependent re-gridding (reference kan1.py:167-212): the knots move to the batch's per-feature quantiles
+        (blended with a uniform grid by grid_eps) and the spline coefficients are re-fitted by least squares so that the
+        spline part reproduces its old outputs on x.  A maintenance step between batches, not part of the per-batch path:
+        like reset_parameters it runs on the host in f32 (sort + a batched least-squares solve of `in_features` small systems)
+        and writes the results back into the device-resident buffers the kernels read."""
+        assert x.dim() == 2 and x.size(1) == self.in_features
+        dev = self.grid.device
+        xh = x.detach().float().cpu()
+        batch = xh.size(0)
+        host = types.SimpleNamespace(grid=self.grid.detach().float().cpu(), spline_order=self.spline_order)   # for _b_splines_host
+        splines = KANLinear._b_splines_host(host, xh).permute(1, 0, 2)                      # (in, batch, coeff)
+        coeff = self.scaled_spline_weight.detach().float().cpu().permute(1, 2, 0)           # (in, coeff, out)
+        y = torch.bmm(splines, coeff).permute(1, 0, 2)                                      # (batch, in, out)
+        xs = torch.sort(xh, dim=0)[0]
+        adaptive = xs[torch.linspace(0, batch - 1, self.grid_size + 1, dtype=torch.int64)]
+        step = (xs[-1] - xs[0] + 2 * margin) / self.grid_size
+        uniform = torch.arange(self.grid_size + 1, dtype=torch.float32).unsqueeze(1) * step + xs[0] - margin
+        grid = self.grid_eps * uniform + (1 - self.grid_eps) * adaptive
+        k = self.spline_order
+        grid = torch.cat([grid[:1] - step * torch.arange(k, 0, -1).unsqueeze(1), grid,
+                          grid[-1:] + step * torch.arange(1, k + 1).unsqueeze(1)], dim=0)
+        host.grid = grid.T.contiguous()
+        A = KANLinear._b_splines_host(host, xh).transpose(0, 1)
+        sol = torch.linalg.lstsq(A, y.transpose(0, 1)).solution
+        self.grid.copy_(host.grid.to(dev))
+        self.spline_weight.data.copy_(sol.permute(2, 0, 1).contiguous().to(dev))
 
     def regularization_loss(self, regularize_activation=1.0, regularize_entropy=1.0):
         return K.kan_regularization(self.spline_weight, regularize_activation, regularize_entropy)
@@ -96,9 +123,9 @@ class KAN1(torch.nn.Module):
     def forward(self, x, update_grid=False):
         if x.numel() == 0:
             return torch.zeros((*x.shape[:-1], self.output_dim), device=x.device)
-        if update_grid:
-            raise NotImplementedError("update_grid is not implemented")
         for layer in self.layers:
+            if update_grid:
+                layer.update_grid(x)
             x = layer(x)
         return x
 

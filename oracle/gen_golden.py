@@ -164,6 +164,23 @@ def gen_kan_moe():
          gw={k: p.grad for k, p in m.named_parameters() if p.grad is not None})
 
 
+def gen_kan_update_grid():
+    """KANLinear.update_grid / KAN1.forward(update_grid=True) of the reference (kan1.py:167-212, 275-283) run directly:
+    new knot grid, re-fitted spline coefficients and the layer's output after the update"""
+    from ConNexT.models.block import kan1
+    x = rnd((40, 16), 52, 0.9)
+    lay = kan1.KANLinear(16, 12)
+    load_procedural(lay, SEED + 87)
+    before = lay(x)
+    lay.update_grid(x)
+    save("kan_update_grid", x=x, out_before=before, grid=lay.grid, spline_weight=lay.spline_weight, out_after=lay(x))
+    net = kan1.KAN1([16, 24, 8])
+    load_procedural(net, SEED + 88)
+    y = net(x, update_grid=True)
+    save("kan1_stack_update_grid", x=x, out=y, grid0=net.layers[0].grid, grid1=net.layers[1].grid,
+         spline0=net.layers[0].spline_weight, spline1=net.layers[1].spline_weight)
+
+
 def install_kan_head_standin():
     """`ikan.GroupKAN.GroupKANLinear` is an external package absent from the reference tree and from this container
     (modules/heads.py:7-25 resolves it to None and build_kan_head raises).  For the classifier_type="kan" vectors the
@@ -395,7 +412,7 @@ def main():
     install_torchvision_standin()
     sys.path.insert(0, REF)
     groups = {"fusion": lambda tmp: gen_fusion(), "heads": lambda tmp: gen_heads(), "ibfa": lambda tmp: gen_ibfa(),
-              "kan_moe": lambda tmp: gen_kan_moe(), "kan_head": gen_kan_head, "losses": gen_losses, "bert": gen_bert,
+              "kan_moe": lambda tmp: gen_kan_moe(), "kan_update_grid": lambda tmp: gen_kan_update_grid(), "kan_head": gen_kan_head, "losses": gen_losses, "bert": gen_bert,
               "e2e_baseline": gen_e2e_baseline,
               "e2e_mibf": gen_e2e_mibf, "convnext": gen_convnext}
     want = sys.argv[1:] or list(groups)          # optional: regenerate only the named groups

@@ -307,3 +307,69 @@ def test_product_param_counts_headline():
     assert sum(p.numel() for p in fb.BilinearFusionModule(768, 256).parameters()) == 164864
     from mibf_net.attention import MultiHeadCrossAttention_v2
     assert sum(p.numel() for p in MultiHeadCrossAttention_v2(768, 1).parameters()) == 3543552
+
+
+def test_oracle_kan_update_grid_matches_reference_vectors():
+    """KANLinear.update_grid / KAN1.forward(update_grid=True) (reference kan1.py:167-212, 275-283): new knots, re-fitted
+    coefficients and the layer output after the update, against vectors made by running the reference"""
+    import numpy as np
+    g = np.load(os.path.join(gc.GOLDEN, "kan_update_grid.npz"))
+    x = torch.from_numpy(g["x"])
+    lay = load_procedural(om.OKANLinear(16, 12), gc.SEED + 87)
+    assert torch.allclose(lay(x), torch.from_numpy(g["out_before"]), atol=1e-5)
+    lay.update_grid(x)
+    assert torch.allclose(lay.grid, torch.from_numpy(g["grid"]), atol=1e-6)
+    assert torch.allclose(lay.spline_weight, torch.from_numpy(g["spline_weight"]), atol=2e-4, rtol=1e-3)
+    assert torch.allclose(lay(x), torch.from_numpy(g["out_after"]), atol=1e-4)
+
+
+def test_pretrained_weight_files_load_into_the_towers(tmp_path, monkeypatch):
+    """The reference's weight-file branches (encoder.py:44-52 `image_weights_path` / torchvision hub cache;
+    BertModel.from_pretrained on a local HF directory holding model.safetensors or pytorch_model.bin, encoder.py:123,
+    mibf_net/bert.py:9): the product towers end up with exactly the tensors in the files (no kernels run: CPU test)."""
+    import encoder as product_encoder
+    from transformers import BertConfig
+    from transformers import BertModel as HFBert
+    from hamspine.nn.bert import BertModel
+    # --- HF directory written by transformers itself: model.safetensors, then pytorch_model.bin ------------------------
+    hf = HFBert(BertConfig(**gc.TINY_BERT)).eval()
+    for safe in (True, False):
+        d = str(tmp_path / f"hf_{int(safe)}")
+        if safe:
+            hf.save_pretrained(d)                                          # this transformers writes model.safetensors
+        else:                                                              # the older layout: config.json + pytorch_model.bin
+            hf.config.save_pretrained(d)
+            torch.save(hf.state_dict(), os.path.join(d, "pytorch_model.bin"))
+        assert os.path.exists(os.path.join(d, "model.safetensors" if safe else "pytorch_model.bin"))
+        assert not os.path.exists(os.path.join(d, "pytorch_model.bin" if safe else "model.safetensors"))
+        pm = BertModel.from_pretrained(d)
+        want = {k: v for k, v in hf.state_dict().items() if "position_ids" not in k}
+        got = pm.state_dict()
+        assert set(want) <= set(got)
+        for k, v in want.items():
+            assert torch.equal(got[k], v), k
+    with pytest.raises(FileNotFoundError):
+        BertModel.from_pretrained(str(tmp_path / "nowhere"))
+    # --- torchvision-format ResNet .pth through image_weights_path, and through the hub cache (pretrained=True) ----------
+    o = load_procedural(towers.oresnet("resnet18", num_classes=1000), 77)
+    sd = o.state_dict()                                    # torchvision key layout (conv1, bn1, layer1.0.conv1, ..., fc)
+    pth = str(tmp_path / "resnet18.pth")
+    torch.save(sd, pth)
+    enc = product_encoder.ImageEncoder(feature_dim=64, pretrained=False, weights_path=pth, backbone="resnet18")
+    got = enc.state_dict()
+    for k, v in sd.items():
+        if k.startswith("fc."):
+            continue                                       # the tower drops the classifier (encoder.py:54)
+        assert torch.equal(got["model." + k], v), k
+    assert torch.equal(got["stem.0.weight"], sd["conv1.weight"])         # alias key family of the reference
+    with pytest.raises(FileNotFoundError):
+        product_encoder.ImageEncoder(pretrained=False, weights_path=str(tmp_path / "missing.pth"), backbone="resnet18")
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path / "torch_home"))
+    with pytest.raises(FileNotFoundError):                 # no cached ImageNet file and no network: refuse, never download
+        product_encoder.ImageEncoder(pretrained=True, backbone="resnet18")
+    cache = os.path.dirname(product_encoder._hub_cache_file("x"))
+    os.makedirs(cache)
+    name = product_encoder._BACKBONES["resnet18"][2]
+    torch.save(sd, os.path.join(cache, name))
+    enc2 = product_encoder.ImageEncoder(pretrained=True, backbone="resnet18")
+    assert torch.equal(enc2.state_dict()["model.layer4.1.conv2.weight"], sd["layer4.1.conv2.weight"])

@@ -892,3 +892,25 @@ def test_full_size_c2_size_independent_properties(tmp_path):
         err = (grads[1][k] - 2.0 * g1).abs().max().item()
         assert err <= 4 * spread + 1e-6 * g1.abs().max().item(), f"{k}: |g(2L) - 2 g(L)| = {err:.3e}, run-to-run {spread:.3e}"
         worst = max(worst, err)
+
+
+def test_kan_update_grid_matches_reference_vectors():
+    """KANLinear.update_grid and KAN1.forward(update_grid=True) (reference kan1.py:167-212, 275-283; a between-batches
+    maintenance step that runs on the host and writes the device buffers): knots, coefficients and the outputs the HIP
+    kernels produce from them afterwards, against vectors made by running the reference"""
+    import numpy as np
+    from ConNexT.models.block import kan1
+    g = np.load(os.path.join(gc.GOLDEN, "kan_update_grid.npz"))
+    x = torch.from_numpy(g["x"]).to(DEV)
+    lay = load_procedural(kan1.KANLinear(16, 12), gc.SEED + 87).to(DEV)
+    assert torch.allclose(lay(x).cpu(), torch.from_numpy(g["out_before"]), atol=1e-5)
+    lay.update_grid(x)
+    assert torch.allclose(lay.grid.cpu(), torch.from_numpy(g["grid"]), atol=1e-6)
+    assert torch.allclose(lay.spline_weight.detach().cpu(), torch.from_numpy(g["spline_weight"]), atol=2e-4, rtol=1e-3)
+    assert torch.allclose(lay(x).cpu(), torch.from_numpy(g["out_after"]), atol=1e-4)
+    g2 = np.load(os.path.join(gc.GOLDEN, "kan1_stack_update_grid.npz"))
+    net = load_procedural(kan1.KAN1([16, 24, 8]), gc.SEED + 88).to(DEV)
+    y = net(torch.from_numpy(g2["x"]).to(DEV), update_grid=True)
+    assert torch.allclose(net.layers[0].grid.cpu(), torch.from_numpy(g2["grid0"]), atol=1e-6)
+    assert torch.allclose(net.layers[1].grid.cpu(), torch.from_numpy(g2["grid1"]), atol=1e-5)
+    assert torch.allclose(y.cpu(), torch.from_numpy(g2["out"]), atol=2e-4)
