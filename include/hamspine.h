@@ -253,6 +253,10 @@ hs_status hs_cast_f32_to_bf16_multi(int32_t count, const float* const* src, void
    Used by the BertLayer backward to turn its weight gradients (dY^T X, reduction over the row index of both operands)
    into K-contiguous GEMMs; replaces nothing in the reference (torch.nn.Linear's backward is one cuBLAS call there). */
 hs_status hs_transpose_bf16(const void* src, void* dst, int32_t R, int32_t C, int64_t ld_src, int64_t ld_dst, void* stream);
+/* the same for up to HS_TRANSPOSE_MAX matrices per launch (entries beyond that go to further launches) */
+#define HS_TRANSPOSE_MAX 8
+hs_status hs_transpose_bf16_multi(int32_t count, const void* const* src, void* const* dst, const int32_t* R, const int32_t* C,
+                                  const int64_t* ld_src, const int64_t* ld_dst, void* stream);
 /* out = a*x + b*y (y may be NULL); dtypes are HS_F32/HS_BF16 for inputs (shared) and output. */
 hs_status hs_axpby(int32_t in_dtype, int32_t out_dtype, const void* x, const void* y, void* out, int64_t n, float a,
                    float b, void* stream);

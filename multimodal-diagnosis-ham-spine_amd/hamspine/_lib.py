@@ -190,6 +190,7 @@ def _declare(l):
     l.hs_cast_f32_to_bf16_multi.argtypes = [i32, P(vp), P(vp), P(i64), vp]
     l.hs_axpby.argtypes = [i32, i32, vp, vp, vp, i64, f32, f32, vp]
     l.hs_transpose_bf16.argtypes = [vp, vp, i32, i32, i64, i64, vp]
+    l.hs_transpose_bf16_multi.argtypes = [i32, P(vp), P(vp), P(i32), P(i32), P(i64), P(i64), vp]
     l.hs_dropout.argtypes = [i32, vp, vp, i64, f32, u64, vp]
     l.hs_relu_fwd.argtypes = [i32, vp, vp, i64, vp]
     l.hs_relu_bwd.argtypes = [i32, vp, vp, vp, i64, vp]

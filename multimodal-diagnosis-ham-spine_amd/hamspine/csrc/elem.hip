@@ -720,11 +720,10 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const T* __restrict_
 // of a BertLayer) and running the weight gradients as K-contiguous GEMMs is the faster total.
 // 64x64 tiles; LDS image of 32-bit words with a 33-word pitch (conflict-free both ways); 16-byte global accesses.
 // ============================================================================================
-__global__ __launch_bounds__(256) void transpose_bf16_kernel(const unsigned short* __restrict__ src,
-                                                             unsigned short* __restrict__ dst, int R, int Cc, long long lds_,
-                                                             long long ldd) {
-    __shared__ unsigned tile[64][33];
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+__device__ __forceinline__ void transpose_bf16_tile(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
+                                                    int R, int Cc, long long lds_, long long ldd, int bx, int by,
+                                                    unsigned (*tile)[33]) {
+    const int r0 = by * 64, c0 = bx * 64;
     for (int i = threadIdx.x; i < 512; i += 256) {
         const int r = i >> 3, ch = i & 7;
         u32x4 v = {0u, 0u, 0u, 0u};
@@ -745,6 +744,30 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const unsigned shor
         const u32x4 o = {e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
         *(u32x4*)(dst + (long long)(c0 + j) * ldd + r0 + k * 8) = o;
     }
+}
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const unsigned short* __restrict__ src,
+                                                             unsigned short* __restrict__ dst, int R, int Cc, long long lds_,
+                                                             long long ldd) {
+    __shared__ unsigned tile[64][33];
+    transpose_bf16_tile(src, dst, R, Cc, lds_, ldd, blockIdx.x, blockIdx.y, tile);
+}
+// several matrices in one grid (a BertLayer's backward transposes four saved activations and three weight copies before it
+// starts: seven 7 us launches become one)
+struct TransposeTable {
+    const unsigned short* src[HS_TRANSPOSE_MAX];
+    unsigned short* dst[HS_TRANSPOSE_MAX];
+    int R[HS_TRANSPOSE_MAX], C[HS_TRANSPOSE_MAX];
+    long long ld_src[HS_TRANSPOSE_MAX], ld_dst[HS_TRANSPOSE_MAX];
+    int first[HS_TRANSPOSE_MAX + 1];      // first workgroup of entry i; first[count] = grid size
+    int count;
+};
+__global__ __launch_bounds__(256) void transpose_bf16_multi_kernel(const TransposeTable t) {
+    __shared__ unsigned tile[64][33];
+    int e = 0;
+    for (int i = 1; i < t.count; ++i) e += (int)blockIdx.x >= t.first[i];
+    const int local = blockIdx.x - t.first[e];
+    const int tx = (t.C[e] + 63) / 64;
+    transpose_bf16_tile(t.src[e], t.dst[e], t.R[e], t.C[e], t.ld_src[e], t.ld_dst[e], local % tx, local / tx, tile);
 }
 
 // ============================================================================================
@@ -1231,6 +1254,33 @@ hs_status hs_transpose_bf16(const void* src, void* dst, int32_t R, int32_t Cc, i
     hipLaunchKernelGGL(transpose_bf16_kernel, dim3(ceil_div(Cc, 64), ceil_div(R, 64)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)src, (unsigned short*)dst, R, Cc, (long long)ld_src, (long long)ld_dst);
     HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_transpose_bf16_multi(int32_t count, const void* const* src, void* const* dst, const int32_t* R, const int32_t* Cc,
+                                  const int64_t* ld_src, const int64_t* ld_dst, void* stream) {
+    HS_REQUIRE(count >= 0 && (count == 0 || (src && dst && R && Cc && ld_src && ld_dst)), "transpose_bf16_multi: bad argument");
+    for (int base = 0; base < count; base += HS_TRANSPOSE_MAX) {
+        TransposeTable t;
+        memset(&t, 0, sizeof(t));
+        t.count = std::min(HS_TRANSPOSE_MAX, count - base);
+        int blocks = 0;
+        for (int i = 0; i < t.count; ++i) {
+            const int k = base + i;
+            HS_REQUIRE(src[k] && dst[k] && R[k] > 0 && Cc[k] > 0 && R[k] % 8 == 0 && Cc[k] % 8 == 0 && ld_src[k] % 8 == 0 &&
+                           ld_dst[k] % 8 == 0 && ld_src[k] >= Cc[k] && ld_dst[k] >= R[k] &&
+                           (((uintptr_t)src[k] | (uintptr_t)dst[k]) & 15) == 0,
+                       "transpose_bf16_multi: entry %d: dims / leading dimensions must be multiples of 8 and bases 16-byte aligned", k);
+            t.src[i] = (const unsigned short*)src[k];
+            t.dst[i] = (unsigned short*)dst[k];
+            t.R[i] = R[k]; t.C[i] = Cc[k];
+            t.ld_src[i] = ld_src[k]; t.ld_dst[i] = ld_dst[k];
+            t.first[i] = blocks;
+            blocks += ceil_div(Cc[k], 64) * ceil_div(R[k], 64);
+        }
+        t.first[t.count] = blocks;
+        hipLaunchKernelGGL(transpose_bf16_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);
+        HS_LAUNCH_CHECK();
+    }
     return HS_OK;
 }
 hs_status hs_cross_entropy(const float* logits, const int64_t* labels, const float* weight, float label_smoothing,

@@ -121,6 +121,28 @@ def test_transpose_bf16(R, Cc):
     assert torch.equal(y.cpu(), x.cpu().T.contiguous())
 
 
+def test_transpose_bf16_multi():
+    """several matrices per launch (ragged 64-tile edges, strided sources, more entries than one launch holds)"""
+    import ctypes as C
+    shapes = [(4096, 3072), (768, 3072), (3072, 768), (200, 72), (8, 8), (136, 1000), (2304, 768), (64, 64), (72, 200), (40, 24)]
+    xs, ys = [], []
+    for i, (R, Cc) in enumerate(shapes):
+        ld = Cc + (16 if i % 3 == 1 else 0)
+        full = torch.randn(R, ld, generator=torch.Generator().manual_seed(i)).bfloat16().to(DEV)
+        xs.append(full)
+        ys.append(torch.full((Cc, R), float("nan"), dtype=torch.bfloat16, device=DEV))
+    n = len(shapes)
+    src = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    dst = (C.c_void_p * n)(*[y.data_ptr() for y in ys])
+    Rs = (C.c_int32 * n)(*[s[0] for s in shapes])
+    Cs = (C.c_int32 * n)(*[s[1] for s in shapes])
+    lds = (C.c_int64 * n)(*[x.shape[1] for x in xs])
+    ldd = (C.c_int64 * n)(*[s[0] for s in shapes])
+    L.check(L.lib().hs_transpose_bf16_multi(n, src, dst, Rs, Cs, lds, ldd, rt.stream()), "hs_transpose_bf16_multi")
+    for (R, Cc), x, y in zip(shapes, xs, ys):
+        assert torch.equal(y.cpu(), x[:, :Cc].cpu().T.contiguous()), (R, Cc)
+
+
 def test_bert_weight_gradients_transposed_operands_equal_row_major():
     """BertLayer backward in bf16: dW from transposed (K-contiguous) copies of dY and X, with the bias gradients as row sums
     of dY^T, against the row-major form: f32 accumulation in both, the K order inside a tile differs -> 1e-5 relative"""
