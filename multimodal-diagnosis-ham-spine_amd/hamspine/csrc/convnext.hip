@@ -52,6 +52,9 @@ __global__ __launch_bounds__(256) void dw_pack_filter_kernel(const float* __rest
 // One thread: 4 channels x TW consecutive output columns.  Each input vector is loaded once per filter row and
 // feeds up to KS outputs from registers, so L1 traffic is ~(TW+KS-1)/TW loads per output per row instead of KS.
 // ------------------------------------------------------------------------------------------------------------
+// (A branch-free variant of this kernel -- padding through out-of-range buffer offsets, as in dwconv_wgrad_kernel below --
+// measured 54.7 vs 35.6 us on the 14 x 14 x 512 stage: here the skipped taps are real work saved and the loads of a row
+// already issue together, so the predicated form stays.)
 template <typename T, int KS, int TW>
 __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, const float* __restrict__ wt,
                                                      const float* __restrict__ bias, T* __restrict__ y, int N, int H,
@@ -106,58 +109,96 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
 
 // ------------------------------------------------------------------------------------------------------------
 // filter / bias gradient: dw[c][r][s] = sum_{n,h,w} dy[n,h,w,c] * x[n,h+r-pad,w+s-pad,c];  db[c] = sum dy.
-// One wave per (64-channel group, chunk of image rows); lane = channel.  Along w the KS-wide input window lives
-// in registers (one new x load and one dy load per position and filter row).  Chunk partials go to ws, a second
-// kernel sums them in a fixed order (deterministic).
+// One wave per (128-channel group, chunk of image rows); a lane owns TWO adjacent channels (4-byte bf16 pair loads).
+// A row is walked in segments of SW columns: the dy segment and, per filter row, the SW + KS - 1 inputs under it are
+// fetched by INDEPENDENT loads into registers before any of them is used.  (The first version slid a KS-wide window along
+// w with one dy load per column consumed in the same iteration: every iteration waited a full memory round trip, 343 of
+// them in a row for a 14 x 14 map -- 190 us per ConvNeXt stage-3 block against a 26 MB / 0.3 GFMA problem.)  Chunk
+// partials go to ws, a second kernel sums them in a fixed order (deterministic).
 // ------------------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void load2(const float* p, float* f) {
+    const f32x2 v = *(const f32x2*)p;
+    f[0] = v[0];
+    f[1] = v[1];
+}
+__device__ __forceinline__ void load2(const bf16_t* p, float* f) {
+    const unsigned v = *(const unsigned*)p;
+    f[0] = __uint_as_float(v << 16);
+    f[1] = __uint_as_float(v & 0xffff0000u);
+}
+// two adjacent channels through a buffer descriptor: out-of-range offsets (kOOB) read as zeros, so image borders and
+// row tails need no branch and the loads of a batch issue back to back
+template <typename T>
+__device__ __forceinline__ void bload2(__amdgpu_buffer_rsrc_t rs, unsigned off, float* f) {
+    if constexpr (sizeof(T) == 2) {
+        const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
+        f[0] = __uint_as_float(v << 16);
+        f[1] = __uint_as_float(v & 0xffff0000u);
+    } else {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
+        f[0] = __uint_as_float(v[0]);
+        f[1] = __uint_as_float(v[1]);
+    }
+}
 template <typename T, int KS>
 __global__ __launch_bounds__(64) void dwconv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           float* __restrict__ ws, int N, int H, int W, int C) {
     constexpr int PAD = KS / 2;
     constexpr int TAPS = KS * KS;
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    const bool live = c < C;
-    float acc[KS][KS];
-    float accb = 0.f;
+    constexpr int SW = 16;
+    const int c = (blockIdx.x * 64 + threadIdx.x) * 2;
+    if (c >= C) return;                    // C % 4 == 0: a live lane owns two live channels
+    float acc[KS][KS][2];
+    float accb[2] = {0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < KS; ++r)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) acc[r][s] = 0.f;
-    if (live) {
-        const int rows = N * H;
-        for (int row = blockIdx.y; row < rows; row += gridDim.y) {
-            const int n = row / H, h = row - n * H;
-            const T* gr = dy + ((size_t)row * W) * C + c;
+        for (int s = 0; s < KS; ++s) acc[r][s][0] = acc[r][s][1] = 0.f;
+    const int rows = N * H;
+    const unsigned long long bytes = (unsigned long long)rows * W * C * sizeof(T);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (unsigned)min(bytes, 0x7fffff00ull));
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(dy, (unsigned)min(bytes, 0x7fffff00ull));
+    const unsigned pix = (unsigned)C * sizeof(T);                 // bytes per pixel
+    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int n = row / H, h = row - n * H;
+        const unsigned gbase = (unsigned)row * W * pix + c * sizeof(T);
+        for (int w0 = 0; w0 < W; w0 += SW) {
+            float g[SW][2];
+#pragma unroll
+            for (int j = 0; j < SW; ++j) bload2<T>(rg, w0 + j < W ? gbase + (unsigned)(w0 + j) * pix : kOOB, g[j]);
+#pragma unroll
+            for (int j = 0; j < SW; ++j) {
+                accb[0] += g[j][0];
+                accb[1] += g[j][1];
+            }
 #pragma unroll
             for (int r = 0; r < KS; ++r) {
                 const int ih = h + r - PAD;
-                if (ih < 0 || ih >= H) continue;
-                const T* xr = x + ((size_t)(n * H + ih) * W) * C + c;
-                float win[KS];
+                const bool rok = ih >= 0 && ih < H;               // (wave-uniform; a dead row reads zeros)
+                const unsigned xbase = (unsigned)((n * H + ih) * W) * pix + c * sizeof(T);
+                float xv[SW + KS - 1][2];
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const int iw = s - PAD;
-                    win[s] = (iw >= 0 && iw < W) ? to_f32(xr[(size_t)iw * C]) : 0.f;
+                for (int j = 0; j < SW + KS - 1; ++j) {
+                    const int iw = w0 - PAD + j;
+                    bload2<T>(rx, (rok && iw >= 0 && iw < W) ? xbase + (unsigned)iw * pix : kOOB, xv[j]);
                 }
-                for (int w = 0; w < W; ++w) {
-                    const float g = to_f32(gr[(size_t)w * C]);
-                    if (r == PAD) accb += g;
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) acc[r][s] = fmaf(g, win[s], acc[r][s]);
+                for (int j = 0; j < SW; ++j)
 #pragma unroll
-                    for (int s = 0; s < KS - 1; ++s) win[s] = win[s + 1];
-                    const int iw = w + KS - PAD;
-                    win[KS - 1] = iw < W ? to_f32(xr[(size_t)iw * C]) : 0.f;
-                }
+                    for (int s_ = 0; s_ < KS; ++s_) {
+                        acc[r][s_][0] = fmaf(g[j][0], xv[j + s_][0], acc[r][s_][0]);
+                        acc[r][s_][1] = fmaf(g[j][1], xv[j + s_][1], acc[r][s_][1]);
+                    }
             }
         }
-        float* o = ws + (size_t)blockIdx.y * (TAPS + 1) * C + c;
-#pragma unroll
-        for (int r = 0; r < KS; ++r)
-#pragma unroll
-            for (int s = 0; s < KS; ++s) o[(size_t)(r * KS + s) * C] = acc[r][s];
-        o[(size_t)TAPS * C] = accb;
     }
+    float* o = ws + (size_t)blockIdx.y * (TAPS + 1) * C + c;
+#pragma unroll
+    for (int r = 0; r < KS; ++r)
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) *(f32x2*)(o + (size_t)(r * KS + s_) * C) = f32x2{acc[r][s_][0], acc[r][s_][1]};
+    *(f32x2*)(o + (size_t)TAPS * C) = f32x2{accb[0], accb[1]};
 }
 __global__ __launch_bounds__(256) void dwconv_wgrad_final_kernel(const float* __restrict__ ws, int chunks, int C, int taps,
                                                                  float* __restrict__ dw, float* __restrict__ db) {
@@ -229,7 +270,7 @@ static int dwconv_bwd_t(const void* x, const float* w, const void* dy, void* dx,
     if (dw) {
         float* part = ws + (size_t)C * taps;
         const int chunks = dw_chunks(N, H, C);
-        const dim3 grid((C + 63) / 64, chunks);
+        const dim3 grid((C + 127) / 128, chunks);
         if (ks == 7)
             hipLaunchKernelGGL((dwconv_wgrad_kernel<T, 7>), grid, dim3(64), 0, s, (const T*)x, (const T*)dy, part, N, H, W, C);
         else if (ks == 5)
@@ -267,24 +308,55 @@ __global__ __launch_bounds__(256) void layerscale_fwd_kernel(const T* __restrict
         store4(out + m * C + c, o);
     }
 }
-// du = gamma * rs * dy ; partial dgamma[c] = sum_m rs * dy * u  (thread per column, blockIdx.y strides rows)
+// du = gamma * rs * dy ; partial dgamma[c] = sum_m rs * dy * u.  A thread owns FOUR adjacent channels (8-byte bf16 accesses;
+// the first version owned one: 2-byte accesses and, for C = 128, half a block idle -- 245 us on the 200704 x 128 stage); a
+// block covers 256 / (C/4) rows per pass, blockIdx.y strides the row groups, and the rows of a block fold through LDS in a
+// fixed order (deterministic).
 template <typename T>
 __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ u,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ rowscale, int rps,
                                                              T* __restrict__ du, float* __restrict__ ws, long long M,
                                                              int C) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const float g = gamma[c];
-    float acc = 0.f;
-    for (long long m = blockIdx.y; m < M; m += gridDim.y) {
-        const float rs = rowscale ? rowscale[m / rps] : 1.f;
-        const float d = to_f32(dy[m * C + c]) * rs;
-        acc = fmaf(d, to_f32(u[m * C + c]), acc);
-        if (du) du[m * C + c] = from_f32<T>(d * g);
+    __shared__ float sh[256][4];
+    const int C4 = C >> 2;
+    const int ncol = min(256, C4 - (int)blockIdx.x * 256);      // 4-channel columns of this block
+    const int rpb = 256 / ncol;                                 // rows per pass
+    const int tid = threadIdx.x;
+    const int rsub = tid / ncol, col = tid - rsub * ncol;
+    const int c = ((int)blockIdx.x * 256 + col) * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rsub < rpb) {
+        float gv[4];
+        load4(gamma + c, gv);
+        for (long long m = (long long)blockIdx.y * rpb + rsub; m < M; m += (long long)gridDim.y * rpb) {
+            const float rs = rowscale ? rowscale[m / rps] : 1.f;
+            float d[4], uv[4];
+            load4(dy + m * C + c, d);
+            load4(u + m * C + c, uv);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                d[k] *= rs;
+                acc[k] = fmaf(d[k], uv[k], acc[k]);
+            }
+            if (du) {
+                float o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = d[k] * gv[k];
+                store4(du + m * C + c, o);
+            }
+        }
     }
-    ws[(size_t)blockIdx.y * C + c] = acc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sh[tid][k] = acc[k];
+    __syncthreads();
+    if (rsub == 0) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < rpb; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] += sh[r * ncol + col][k];
+        store4(ws + (size_t)blockIdx.y * C + c, t);
+    }
 }
 __global__ __launch_bounds__(256) void partial_colsum_final_kernel(const float* __restrict__ ws, int gy, int C,
                                                                    float* __restrict__ out) {
@@ -319,7 +391,7 @@ template <typename T>
 static int layerscale_bwd_t(const void* dy, const void* u, const float* gamma, const float* rowscale, int rps, void* du,
                             float* dgamma, float* ws, long long M, int C, hipStream_t s) {
     const int gy = ls_gy(M);
-    hipLaunchKernelGGL(layerscale_bwd_kernel<T>, dim3((C + 255) / 256, gy), dim3(256), 0, s, (const T*)dy, (const T*)u, gamma,
+    hipLaunchKernelGGL(layerscale_bwd_kernel<T>, dim3((C / 4 + 255) / 256, gy), dim3(256), 0, s, (const T*)dy, (const T*)u, gamma,
                        rowscale, rps, (T*)du, ws, M, C);
     HS_LAUNCH_CHECK();
     hipLaunchKernelGGL(partial_colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, ws, gy, C, dgamma);
@@ -430,6 +502,7 @@ hs_status hs_dwconv_fwd(int32_t dtype, const void* x, const float* w, const floa
                         int32_t W, int32_t C, int32_t ksize, void* ws, int64_t ws_bytes, void* stream) {
     HS_REQUIRE(x && w && y && ws, "dwconv: null argument");
     HS_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "dwconv: C=%d must be a positive multiple of 4", C);
+    HS_REQUIRE((long long)N * H * W * C * (dtype == HS_BF16 ? 2 : 4) < 0x7fffff00ll, "dwconv: activation larger than 2 GiB");
     HS_REQUIRE(ksize == 3 || ksize == 5 || ksize == 7, "dwconv: kernel size %d not in {3,5,7}", ksize);
     HS_REQUIRE(ws_bytes >= (int64_t)ksize * ksize * C * 4, "dwconv: workspace too small");
     HS_REQUIRE((long long)N * H * W * C < (1ll << 40), "dwconv: image too large");
@@ -442,6 +515,7 @@ hs_status hs_dwconv_bwd(int32_t dtype, const void* x, const float* w, const void
     HS_REQUIRE(ksize == 3 || ksize == 5 || ksize == 7, "dwconv_bwd: kernel size %d not in {3,5,7}", ksize);
     HS_REQUIRE(ws_bytes >= hs_dwconv_ws_bytes(N, H, W, C, ksize), "dwconv_bwd: workspace too small");
     HS_REQUIRE(dw || !db, "dwconv_bwd: db needs dw");
+    HS_REQUIRE((long long)N * H * W * C * (dtype == HS_BF16 ? 2 : 4) < 0x7fffff00ll, "dwconv_bwd: activation larger than 2 GiB");
     return CN_DISPATCH_T(dtype, dwconv_bwd_t, x, w, dy, dx, dw, db, N, H, W, C, ksize, (float*)ws, (hipStream_t)stream);
 }
 

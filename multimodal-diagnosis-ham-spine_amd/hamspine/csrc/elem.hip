@@ -326,21 +326,24 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     for (long long r = blockIdx.y; r < M; r += gridDim.y) acc += to_f32(x[r * ld + c]);
     ws[(long long)blockIdx.y * N + c] = acc;
 }
-// 16-byte variant (N, ld multiples of the chunk, base aligned): 64 chunk columns x 4 row lanes per block, the row
-// lanes merged through LDS in a fixed order
+// 16-byte variant (N, ld multiples of the chunk, base aligned): a block covers min(64, N / chunk) chunk columns and
+// 256 / that many rows per pass (narrow matrices -- ConvNeXt's 200704 x 128 -- used to leave 3/4 of a 64-column block idle:
+// 155 us); the row lanes merge through LDS in a fixed order
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const T* __restrict__ x, long long M, int N, int ld,
                                                                  float* __restrict__ ws) {
     constexpr int E = Chunk<T>::N;
-    __shared__ float sh[4][64 * E];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    __shared__ float sh[256][E];
+    const int ncol = min(64, N / E - (int)blockIdx.x * 64);     // chunk columns of this block
+    const int rpb = 256 / ncol;                                 // rows per pass
+    const int tid = threadIdx.x;
+    const int ty = tid / ncol, tx = tid - ty * ncol;
     const int cc = blockIdx.x * 64 + tx;
-    const bool live = cc * E < N;
     float acc[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) acc[e] = 0.f;
-    if (live) {
-        for (long long r = (long long)blockIdx.y * 4 + ty; r < M; r += (long long)gridDim.y * 4) {
+    if (ty < rpb) {
+        for (long long r = (long long)blockIdx.y * rpb + ty; r < M; r += (long long)gridDim.y * rpb) {
             float f[E];
             Chunk<T>::unpack(*(const u32x4*)(x + r * ld + (long long)cc * E), f);
 #pragma unroll
@@ -348,12 +351,15 @@ __global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const T* __rest
         }
     }
 #pragma unroll
-    for (int e = 0; e < E; ++e) sh[ty][tx * E + e] = acc[e];
+    for (int e = 0; e < E; ++e) sh[tid][e] = acc[e];
     __syncthreads();
-    if (ty == 0 && live) {
+    if (ty == 0) {
 #pragma unroll
-        for (int e = 0; e < E; ++e)
-            ws[(long long)blockIdx.y * N + cc * E + e] = (sh[0][tx * E + e] + sh[1][tx * E + e]) + (sh[2][tx * E + e] + sh[3][tx * E + e]);
+        for (int e = 0; e < E; ++e) {
+            float t = 0.f;
+            for (int r = 0; r < rpb; ++r) t += sh[r * ncol + tx][e];
+            ws[(long long)blockIdx.y * N + cc * E + e] = t;
+        }
     }
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ ws, int gy, int N,
@@ -966,12 +972,16 @@ static int mean_tokens_bwd_t(const void* dy, void* dx, int B, int Nt, int H, int
     return HS_OK;
 }
 
-static inline int colsum_gy(long long M) { return (int)std::min<long long>(std::max<long long>(M / 16, 1), 64); }
+// row groups (grid.y): enough blocks to cover the chip also when the matrix is narrow (one or two blocks along x)
+static inline int colsum_gy(long long M, int N) {
+    const long long cap = std::max<long long>(64, 1024 / ceil_div(N, 512));
+    return (int)std::min<long long>(std::max<long long>(M / 16, 1), cap);
+}
 template <typename T>
 static int colsum_t(const void* x, long long M, int N, int ld, float* out, float* ws, long long ws_bytes, int accumulate,
                     hipStream_t s) {
     constexpr int E = Chunk<T>::N;
-    const int gy = colsum_gy(M);
+    const int gy = colsum_gy(M, N);
     HS_REQUIRE(ws && ws_bytes >= (long long)gy * N * 4, "colsum: workspace too small");
     if (N % E == 0 && ld % E == 0 && ((((uintptr_t)x) & 15) == 0))
         hipLaunchKernelGGL(colsum_partial_vec_kernel<T>, dim3(ceil_div(N / E, 64), gy), dim3(256), 0, s, (const T*)x, M, N, ld, ws);
@@ -1182,7 +1192,7 @@ hs_status hs_colsum(int32_t dtype, const void* x, int64_t M, int32_t N, int32_t 
     HS_REQUIRE(x && out && M > 0 && N > 0, "colsum: bad argument");
     return DISPATCH_T(dtype, colsum_t, x, M, N, ld, out, (float*)ws, ws_bytes, accumulate, (hipStream_t)stream);
 }
-int64_t hs_colsum_ws_bytes(int64_t M, int32_t N) { return (int64_t)colsum_gy(M) * N * 4; }
+int64_t hs_colsum_ws_bytes(int64_t M, int32_t N) { return (int64_t)colsum_gy(M, N) * N * 4; }
 hs_status hs_softmax_fwd(int32_t dtype, const float* S, const int64_t* mask, void* P, void* P_drop, int64_t rows,
                          int32_t Lk, int32_t ldS, int32_t ldP, int32_t rows_per_batch, float dropout_p, uint64_t seed,
                          void* stream) {
