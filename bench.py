@@ -128,11 +128,13 @@ RIDGE_FLOP_PER_BYTE = MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)     # 
 
 
 def shape_class(combo, M, N, K, R):
-    """shape classes of the GEMM family (combo: 0 nt 1 nn 2 tn plain; 3 conv fwd, 4 conv dgrad, 5 conv wgrad)"""
-    role = ("fwd", "dgrad", "wgrad")[combo % 3]
+    """shape classes of the GEMM family.  Plain GEMMs by operand layout (combo 0 nt: forward GEMMs and -- on transposed
+    operand / weight copies -- the BERT weight and data gradients; 1 nn: data gradients on row-major weights; 2 tn: weight
+    gradients on row-major operands); convolutions by filter and role (3 forward, 4 data gradient, 5 weight gradient)."""
     if combo < 3:
         bert = (M == 4096 or K == 4096) and min(M, N, K) >= 768 and max(M, N) <= 4096
-        return ("bert_" if bert else "pointwise_") + role        # pointwise = 1x1 convolutions and the small Linear layers
+        return ("bert_" if bert else "pointwise_") + ("nt", "nn", "tn")[combo]   # pointwise = 1x1 convolutions and small Linear layers
+    role = ("fwd", "dgrad", "wgrad")[combo % 3]
     return ("conv3x3_" if R == 3 else "conv7x7_" if R == 7 else "conv1x1s2_") + role
 
 
