@@ -391,6 +391,64 @@ def linear(x, weight, bias=None, act=None, dropout_p=0.0, residual=None, out_dty
     return LinearFn.apply(x, weight, bias, act, float(dropout_p), residual, out_dtype)
 
 
+class MlpGeluFn(Function):
+    """y = gelu(x W1^T + b1) W2^T + b2 as ONE node (the ConvNeXt block's pwconv1 -> GELU -> pwconv2, transformers
+    ConvNextLayer / reference ConNexT/models/ourmodel.py:41-62).  Two Linear nodes computed the same values but ran GELU'
+    as its own pass over the 4x-wide hidden gradient; here the second Linear's data-gradient GEMM applies GELU'(pre) in its
+    epilogue (the BertLayer executor does the same), and both weight copies are cast in one launch."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        rt.need_gpu(x, w1, b1, w2, b2)
+        x = x.contiguous()
+        hid, in_f = w1.shape
+        out_f = w2.shape[0]
+        M = _rows(x)
+        dt = x.dtype
+        hdt = rt.hs_dtype(dt)
+        w1_lp, w2_lp = rt.cast_weights([w1, w2], x.device) if dt == torch.bfloat16 else (None, None)
+        pre = torch.empty(x.shape[:-1] + (hid,), dtype=dt, device=x.device)
+        h = torch.empty_like(pre)
+        y = torch.empty(x.shape[:-1] + (out_f,), dtype=dt, device=x.device)
+        lin1, lin2 = _lin(in_f, hid, w1, b1), _lin(hid, out_f, w2, b2)
+        L.check(_lib().hs_linear_fwd(hdt, rt.p(x), M, in_f, C.byref(lin1), rt.p(w1_lp), rt.p(h), hid, hdt, L.ACT_GELU,
+                                     rt.p(pre), None, hid, 0.0, 0, rt.stream()), "hs_linear_fwd")
+        L.check(_lib().hs_linear_fwd(hdt, rt.p(h), M, hid, C.byref(lin2), rt.p(w2_lp), rt.p(y), out_f, hdt, L.ACT_NONE,
+                                     None, None, out_f, 0.0, 0, rt.stream()), "hs_linear_fwd")
+        ctx.save_for_backward(x, w1, b1, w2, b2, w1_lp, w2_lp, pre, h)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, b1, w2, b2, w1_lp, w2_lp, pre, h = ctx.saved_tensors
+        hid, in_f = w1.shape
+        out_f = w2.shape[0]
+        M = _rows(x)
+        dt = x.dtype
+        hdt = rt.hs_dtype(dt)
+        dy = dy.contiguous()
+        if dy.dtype != dt:
+            dy = dy.to(dt)
+        need = ctx.needs_input_grad
+        dw1, db1 = _grad_like(w1, need[1]), _grad_like(b1, b1 is not None and need[2])
+        dw2, db2 = _grad_like(w2, need[3]), _grad_like(b2, b2 is not None and need[4])
+        dpre = torch.empty_like(pre)                      # gradient wrt the hidden pre-activation
+        dx = torch.empty_like(x) if need[0] else None
+        lin2 = _lin(hid, out_f, w2, b2, dw2, db2)
+        ws = rt.workspace(_lib().hs_linear_bwd_ws_bytes(M, hid, out_f, hdt), x.device)
+        L.check(_lib().hs_linear_bwd(hdt, rt.p(h), M, hid, C.byref(lin2), rt.p(w2_lp), rt.p(dy), out_f, rt.p(dpre), hid, hdt,
+                                     L.MUL_GELU_GRAD, rt.p(pre), hid, None, rt.p(ws), ws.numel(), rt.stream()), "hs_linear_bwd")
+        lin1 = _lin(in_f, hid, w1, b1, dw1, db1)
+        ws = rt.workspace(_lib().hs_linear_bwd_ws_bytes(M, in_f, hid, hdt), x.device)
+        L.check(_lib().hs_linear_bwd(hdt, rt.p(x), M, in_f, C.byref(lin1), rt.p(w1_lp), rt.p(dpre), hid, rt.p(dx), in_f, hdt,
+                                     L.MUL_NONE, None, 0, None, rt.p(ws), ws.numel(), rt.stream()), "hs_linear_bwd")
+        return dx, dw1, db1, dw2, db2
+
+
+def mlp_gelu(x, w1, b1, w2, b2):
+    return MlpGeluFn.apply(x, w1, b1, w2, b2)
+
+
 class LayerNormFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):

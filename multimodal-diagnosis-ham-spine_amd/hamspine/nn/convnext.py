@@ -79,11 +79,17 @@ def _drop_path_scale(x, p, training):
     return (torch.rand(x.shape[0], device=x.device) < keep).to(torch.float32) / keep
 
 
+def _hooked(m):
+    return bool(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None))
+
+
 def _block(x, dw, ln, pw1, pw2, gamma, rowscale):
     y = X.dwconv(x, dw.weight, dw.bias)
     y = ln(y)
-    y = pw1(y, act="gelu")
-    u = pw2(y)
+    if _hooked(pw1) or _hooked(pw2) or pw1.bias is None or pw2.bias is None:
+        u = pw2(pw1(y, act="gelu"))                        # the two Linear modules stay the hookable path
+    else:
+        u = F.mlp_gelu(y, pw1.weight, pw1.bias, pw2.weight, pw2.bias)
     return X.layer_scale_residual(u, gamma, x, rowscale)
 
 
