@@ -296,6 +296,17 @@ hs_status hs_cross_entropy(const float* logits, const int64_t* labels, const flo
 hs_status hs_adam_step_multi(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
                              float* const* exp_avg_sq, const int64_t* n, float lr, float beta1, float beta2, float eps,
                              float weight_decay, int32_t step, int32_t decoupled, float grad_scale, void* stream);
+/* the same, additionally writing bf16 copies of the updated parameters (bf16_shadow[i] may be NULL; the whole array may be
+   NULL): the copies the composites read as weights once registered with hs_weight_shadow_set */
+hs_status hs_adam_step_multi_shadow(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                                    float* const* exp_avg_sq, void* const* bf16_shadow, const int64_t* n, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, int32_t step, int32_t decoupled,
+                                    float grad_scale, void* stream);
+/* bf16 shadow registry: while registered, every composite / tower reads `bf16` (n elements of the weight, same memory order)
+   instead of casting `w` in its forward.  The caller keeps it equal to bf16(w).  bf16 = NULL forgets the entry.  No
+   reference counterpart (torch autocast re-casts weights per call). */
+hs_status hs_weight_shadow_set(const float* w, void* bf16);
+void hs_weight_shadow_clear(void);
 
 /* fused multi-tensor SGD, torch.optim.SGD semantics (the reference's fallback optimizer, scripts/train.py:309):
    g += wd*p; buf = first ? g : momentum*buf + g; g = nesterov ? g + momentum*buf : buf; p -= lr*g.  momentum_buf may be

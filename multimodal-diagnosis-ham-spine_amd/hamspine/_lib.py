@@ -205,6 +205,10 @@ def _declare(l):
     l.hs_bert_embed_bwd.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     l.hs_cross_entropy.argtypes = [vp, vp, vp, f32, i32, i32, vp, vp, vp, vp]
     l.hs_adam_step_multi.argtypes = [i32, P(vp), P(vp), P(vp), P(vp), P(i64), f32, f32, f32, f32, f32, i32, i32, f32, vp]
+    l.hs_adam_step_multi_shadow.argtypes = [i32, P(vp), P(vp), P(vp), P(vp), P(vp), P(i64), f32, f32, f32, f32, f32, i32, i32, f32, vp]
+    l.hs_weight_shadow_set.argtypes = [vp, vp]
+    l.hs_weight_shadow_clear.argtypes = []
+    l.hs_weight_shadow_clear.restype = None
     l.hs_sgd_step_multi.argtypes = [i32, P(vp), P(vp), P(vp), P(i64), f32, f32, f32, i32, i32, f32, vp]
     l.hs_attention_query.argtypes = [P(AttnDesc), P(i64), P(i64)]
     l.hs_attention_fwd.argtypes = [P(AttnDesc), vp, vp, vp, vp, vp, i64, vp, i64, vp]

@@ -5,6 +5,7 @@
 // sizes and pointers cannot drift apart.
 #include <algorithm>
 #include <mutex>
+#include <unordered_map>
 #include <stdlib.h>
 #include "hs_common.h"
 
@@ -669,9 +670,21 @@ struct CastList {
     int64_t n[HS_CAST_MAX];
     int count = 0;
 };
+// bf16 weight SHADOWS: a caller that keeps a bf16 copy of a parameter up to date itself (hamspine.rt: the fused optimizer
+// writes it together with the f32 update, the towers re-cast it when anything else touched the parameter) registers it here by
+// the parameter's address; the composites then read the shadow instead of casting the weight again in every forward.  The
+// slot in the saved arena is still reserved, so an arena layout never depends on what is registered.
+static std::mutex g_shadow_mu;
+static std::unordered_map<const float*, void*> g_shadow;
+static void* shadow_of(const float* w) {
+    std::lock_guard<std::mutex> lk(g_shadow_mu);
+    auto it = g_shadow.find(w);
+    return it == g_shadow.end() ? nullptr : it->second;
+}
 static const void* weight_c(Run& r, CastList& cl, const float* w, long long n) {
     if (r.dt == HS_F32) return w;
     void* d = r.saved.alloc(n * 2);
+    if (void* sh = shadow_of(w)) return sh;
     cl.src[cl.count] = w;
     cl.dst[cl.count] = d;
     cl.n[cl.count] = n;
@@ -1043,7 +1056,10 @@ static int bert_layout(Run& r, const hs_bert_layer_desc& d, BertLayout& L) {
     void* wq = r.saved.alloc(3ll * Hd * Hd * es);
     L.wqkv = wq;
     L.bqkv = (float*)r.saved.alloc(3ll * Hd * 4);
-    if (r.dt == HS_BF16) {
+    char* shq = r.dt == HS_BF16 ? (char*)shadow_of(d.q.w) : nullptr;
+    if (shq && shadow_of(d.k.w) == shq + (long long)Hd * Hd * 2 && shadow_of(d.v.w) == shq + 2ll * Hd * Hd * 2) {
+        L.wqkv = shq;                          // the three shadows are the segments of one [3H][H] buffer (hamspine.tower)
+    } else if (r.dt == HS_BF16) {
         const float* ws3[3] = {d.q.w, d.k.w, d.v.w};
         for (int i = 0; i < 3; ++i) {
             L.casts.src[L.casts.count] = ws3[i];
@@ -1719,6 +1735,19 @@ int64_t hs_linear_bwd_ws_bytes(int64_t M, int32_t in_f, int32_t out_f, int32_t d
     if (linear_wgrad_run(r, nullptr, M, in_f, lin, nullptr, out_f) != HS_OK) return -1;
     if (linear_dgrad_run(r, lin, nullptr, nullptr, M, out_f, nullptr, in_f, dtype, HS_MUL_NONE, nullptr, 0, nullptr) != HS_OK) return -1;
     return r.ws.peak + 1024;
+}
+
+/* bf16 shadow of an f32 weight (see weight_c): `bf16` = NULL forgets the entry */
+hs_status hs_weight_shadow_set(const float* w, void* bf16) {
+    HS_REQUIRE(w != nullptr, "weight_shadow_set: null weight");
+    std::lock_guard<std::mutex> lk(g_shadow_mu);
+    if (bf16) g_shadow[w] = bf16;
+    else g_shadow.erase(w);
+    return HS_OK;
+}
+void hs_weight_shadow_clear(void) {
+    std::lock_guard<std::mutex> lk(g_shadow_mu);
+    g_shadow.clear();
 }
 
 /* sizeof of the ABI structs as this library was compiled (a binding checks its mirror declarations against it) */

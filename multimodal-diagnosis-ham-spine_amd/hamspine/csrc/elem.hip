@@ -848,6 +848,7 @@ struct AdamTable {
     float* m[HS_ADAM_MAX];
     float* v[HS_ADAM_MAX];
     long long n[HS_ADAM_MAX];
+    bf16_t* h[HS_ADAM_MAX];      // optional bf16 shadow of p (the compute-dtype copy the towers read), written with the update
 };
 __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable t, float lr, float beta1, float beta2, float eps,
                                                          float wd, float bc1, float bc2_sqrt, int decoupled,
@@ -867,7 +868,8 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable t, floa
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         pi = pi - (lr / bc1) * (mi / denom);
     };
-    const bool al = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+    bf16_t* h = t.h[e];
+    const bool al = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && (((uintptr_t)h) & 7) == 0;
     const long long n4 = al ? n / 4 : 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         f32x4 pv = ((f32x4*)p)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
@@ -881,11 +883,13 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable t, floa
         ((f32x4*)p)[i] = pv;
         ((f32x4*)m)[i] = mv;
         ((f32x4*)v)[i] = vv;
+        if (h) ((bf16x4*)h)[i] = bf16x4{(bf16_t)pv[0], (bf16_t)pv[1], (bf16_t)pv[2], (bf16_t)pv[3]};
     }
     for (long long i = n4 * 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         float pi = p[i], mi = m[i], vi = v[i];
         upd(pi, g[i], mi, vi);
         p[i] = pi; m[i] = mi; v[i] = vi;
+        if (h) h[i] = (bf16_t)pi;
     }
 }
 
@@ -1327,6 +1331,13 @@ hs_status hs_sgd_step_multi(int32_t count, float* const* params, const float* co
 hs_status hs_adam_step_multi(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
                              float* const* exp_avg_sq, const int64_t* n, float lr, float beta1, float beta2, float eps,
                              float weight_decay, int32_t step, int32_t decoupled, float grad_scale, void* stream) {
+    return hs_adam_step_multi_shadow(count, params, grads, exp_avg, exp_avg_sq, nullptr, n, lr, beta1, beta2, eps, weight_decay, step,
+                                     decoupled, grad_scale, stream);
+}
+hs_status hs_adam_step_multi_shadow(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                                    float* const* exp_avg_sq, void* const* bf16_shadow, const int64_t* n, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, int32_t step, int32_t decoupled,
+                                    float grad_scale, void* stream) {
     HS_REQUIRE(count >= 0 && step >= 1, "adam: bad argument");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
@@ -1341,6 +1352,7 @@ hs_status hs_adam_step_multi(int32_t count, float* const* params, const float* c
             t.m[i] = exp_avg[base + i];
             t.v[i] = exp_avg_sq[base + i];
             t.n[i] = n[base + i];
+            t.h[i] = bf16_shadow ? (bf16_t*)bf16_shadow[base + i] : nullptr;
             mx = std::max<long long>(mx, t.n[i]);
         }
         const int gx = (int)std::min<long long>(std::max<long long>((mx + 4095) / 4096, 1), 256);

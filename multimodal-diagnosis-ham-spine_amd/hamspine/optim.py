@@ -142,7 +142,7 @@ class _FusedAdamBase(torch.optim.Optimizer):
                     "sel": sel, "n": n, "p": arr(sel), "m": arr([self.state[p]["exp_avg"] for p in sel]),
                     "v": arr([self.state[p]["exp_avg_sq"] for p in sel]), "cnt": (C.c_int64 * n)(*[p.numel() for p in sel]),
                     "ptrs": [p.data_ptr() for p in sel], "strides": [p.stride() for p in sel], "step": shared,
-                    "step_host": int(step0), "gptrs": None, "garr": None})
+                    "step_host": int(step0), "gptrs": None, "garr": None, "shadow_epoch": -1, "h": None})
             cache[key] = ent
         b1, b2 = group["betas"]
         for ch in ent["chunks"]:
@@ -167,10 +167,16 @@ class _FusedAdamBase(torch.optim.Optimizer):
                 return self._update(group, ps, grad_scale)
             ch["step_host"] += 1
             ch["step"].fill_(ch["step_host"])                  # 0-dim CPU tensor: no device work
-            L.check(lib.hs_adam_step_multi(
-                n, ch["p"], ch["garr"], ch["m"], ch["v"], ch["cnt"], float(group["lr"]), b1, b2, group["eps"],
+            # bf16 shadows the towers registered for these parameters (hamspine.rt): written by the same kernel, so the next
+            # forward needs no cast.  The pointer table follows the registry's epoch.
+            if ch["shadow_epoch"] != rt.shadow_epoch():
+                hp = [rt.shadow_ptr_of(p) for p in sel]
+                ch["h"] = (C.c_void_p * n)(*hp) if any(hp) else None
+                ch["shadow_epoch"] = rt.shadow_epoch()
+            L.check(lib.hs_adam_step_multi_shadow(
+                n, ch["p"], ch["garr"], ch["m"], ch["v"], ch["h"], ch["cnt"], float(group["lr"]), b1, b2, group["eps"],
                 group["weight_decay"], ch["step_host"], 1 if self._decoupled else 0, float(grad_scale), rt.stream()),
-                "hs_adam_step_multi")
+                "hs_adam_step_multi_shadow")
 
 
 class FusedAdamW(_FusedAdamBase):
@@ -228,4 +234,5 @@ class FusedSGD(torch.optim.Optimizer):
                 L.check(lib.hs_sgd_step_multi(n, arr(sel), arr([p.grad for p in sel]), bufs, cnt, float(group["lr"]), mom,
                                               float(group["weight_decay"]), 1 if group["nesterov"] else 0, 1 if first else 0,
                                               float(grad_scale), rt.stream()), "hs_sgd_step_multi")
+                rt.shadows_stale(sel)      # this kernel does not write the bf16 weight shadows: the next forward re-casts them
         return loss

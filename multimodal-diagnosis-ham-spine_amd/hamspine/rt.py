@@ -170,3 +170,112 @@ def cast_weights(tensors, device):
     cnt = (C.c_int64 * n)(*[t.numel() for t in tensors])
     L.check(L.lib().hs_cast_f32_to_bf16_multi(n, src, dst, cnt, stream()), "hs_cast_f32_to_bf16_multi")
     return outs
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# bf16 weight shadows (bf16 mode): persistent bf16 copies of f32 weights that the towers read instead of casting every
+# weight in every forward (33 cast launches, 0.8 GB per C2 step).  Who keeps a shadow equal to bf16(weight):
+#   * the fused Adam / AdamW step writes it together with the f32 update (hs_adam_step_multi_shadow);
+#   * every tower forward checks its weights' `_version` and address (ensure_shadows) and re-casts, in one launch, the
+#     shadows of weights that anything else touched (load_state_dict, torch.optim, manual init: all bump `_version`);
+#   * our other raw-pointer writer (FusedSGD) calls shadows_stale().
+# The registry on the C side (hs_weight_shadow_set) is keyed by the weight's address.
+# OFF by default (HAMSPINE_WEIGHT_SHADOWS=1 switches it on): measured on C2 it removes the 33 cast launches of a step and
+# changes nothing else -- 12.05-12.11 ms with, 12.02-12.05 ms without: the optimizer's extra 2 B per parameter and the casts'
+# 6 B per parameter both disappear inside an HBM-bound step tail.
+# ------------------------------------------------------------------------------------------------------------------
+import weakref as _weakref
+
+_shadows = {}          # id(param) -> _Shadow
+_shadow_epoch = [0]    # bumped whenever an entry appears, moves or goes (optimizers cache shadow pointers against it)
+
+
+class _Shadow:
+    __slots__ = ("ref", "ptr", "version", "view", "stale", "__weakref__")
+
+
+def shadows_enabled():
+    import os
+    return os.environ.get("HAMSPINE_WEIGHT_SHADOWS", "0") == "1"
+
+
+def shadow_epoch():
+    return _shadow_epoch[0]
+
+
+def shadow_ptr_of(param):
+    """device address of the registered bf16 shadow of `param`, or None"""
+    rec = _shadows.get(id(param))
+    if rec is None or rec.ref() is not param or rec.ptr != param.data_ptr():
+        return None
+    return rec.view.data_ptr()
+
+
+def shadows_stale(params):
+    """a raw-pointer writer changed these parameters without updating their shadows"""
+    for p in params:
+        rec = _shadows.get(id(p))
+        if rec is not None and rec.ref() is p:
+            rec.stale = True
+
+
+_shadow_by_ptr = {}    # weight address -> id(param) of the entry registered for it
+
+
+def _forget_shadow(key, ptr):
+    """drop the entry `key` registered at weight address `ptr` (no-op when that address has since been re-registered)"""
+    if _shadow_by_ptr.get(ptr) != key:
+        return
+    del _shadow_by_ptr[ptr]
+    rec = _shadows.get(key)
+    if rec is not None and rec.ptr == ptr:
+        del _shadows[key]
+    _shadow_epoch[0] += 1
+    try:
+        L.lib().hs_weight_shadow_set(ptr, None)
+    except Exception:      # interpreter shutdown
+        pass
+
+
+def ensure_shadows(groups):
+    """groups: lists of f32 parameters; the shadows of one group are consecutive segments of one bf16 buffer (the fused QKV
+    weight of a BertLayer is read as one [3H][H] matrix).  Registers what is missing and re-casts what is out of date."""
+    if not shadows_enabled():
+        return
+    stale_src, stale_dst = [], []
+    for group in groups:
+        recs = [_shadows.get(id(p)) for p in group]
+        ok = all(r is not None and r.ref() is p and r.ptr == p.data_ptr() for r, p in zip(recs, group))
+        if not ok:
+            for p, r in zip(group, recs):
+                if r is not None:
+                    _forget_shadow(id(p), r.ptr)
+            buf = torch.empty(sum(p.numel() for p in group), dtype=torch.bfloat16, device=group[0].device)
+            off = 0
+            for p in group:
+                rec = _Shadow()
+                rec.ref, rec.ptr, rec.version, rec.stale = _weakref.ref(p), p.data_ptr(), p._version, True
+                rec.view = buf[off:off + p.numel()]
+                off += p.numel()
+                _shadows[id(p)] = rec
+                _shadow_by_ptr[rec.ptr] = id(p)
+                L.check(L.lib().hs_weight_shadow_set(rec.ptr, rec.view.data_ptr()), "hs_weight_shadow_set")
+                _weakref.finalize(p, _forget_shadow, id(p), rec.ptr)
+            _shadow_epoch[0] += 1
+            recs = [_shadows[id(p)] for p in group]
+        for p, r in zip(group, recs):
+            if r.stale or r.version != p._version:
+                stale_src.append(p)
+                stale_dst.append(r.view)
+                r.version, r.stale = p._version, False
+    if stale_src:
+        n = len(stale_src)
+        src = (C.c_void_p * n)(*[t.data_ptr() for t in stale_src])
+        dst = (C.c_void_p * n)(*[t.data_ptr() for t in stale_dst])
+        cnt = (C.c_int64 * n)(*[t.numel() for t in stale_src])
+        L.check(L.lib().hs_cast_f32_to_bf16_multi(n, src, dst, cnt, stream()), "hs_cast_f32_to_bf16_multi")
+
+
+def clear_shadows():
+    for key, rec in list(_shadows.items()):
+        _forget_shadow(key, rec.ptr)

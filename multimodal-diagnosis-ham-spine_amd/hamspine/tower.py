@@ -164,6 +164,8 @@ class _ResnetEntry:
         self.dtype = dtype
         self.arena_version = rt.arena_version()
         self.outstanding = self.peak = 0
+        # bf16 shadows of the block convolutions' filters (the stem's filter is re-packed, not cast): rt.ensure_shadows
+        self.shadow_groups = [[params[i]] for i in range(3, len(params), 3)] if dtype == torch.bfloat16 else []
 
     def valid_for(self, params):
         if self.arena_version != rt.arena_version():
@@ -225,6 +227,7 @@ class ResNetTowerFn(Function):
         ent = cache.get(key)
         if ent is None or not ent.valid_for(params):
             ent = cache[key] = _ResnetEntry(model, image.shape, dtype, training, inference, taps, params, needs, image.device)
+        rt.ensure_shadows(ent.shadow_groups)
         saved = torch.empty(int(ent.plan.saved_bytes), dtype=torch.uint8, device=image.device)
         ws = rt.workspace(int(ent.plan.ws_bytes), image.device)
         L.check(L.lib().hs_resnet_fwd(C.byref(ent.desc), image.data_ptr(), saved.data_ptr(), saved.numel(), ws.data_ptr(),
@@ -374,6 +377,13 @@ class _BertEntry:
         self.shape = (B, Lq, H)
         self.arena_version = rt.arena_version()
         self.outstanding = self.peak = 0
+        # bf16 shadows: q, k, v of a layer as the three segments of one buffer (read as the fused [3H][H] weight), the other
+        # three Linear weights on their own
+        self.shadow_groups = []
+        if dtype == torch.bfloat16:
+            for i in range(len(model.encoder.layer)):
+                b = 5 + 16 * i
+                self.shadow_groups += [[params[b], params[b + 2], params[b + 4]], [params[b + 6]], [params[b + 10]], [params[b + 12]]]
 
     def valid_for(self, params):
         if self.arena_version != rt.arena_version():
@@ -401,6 +411,7 @@ class BertTowerFn(Function):
         ent = cache.get(key)
         if ent is None or not ent.valid_for(params):
             ent = cache[key] = _BertEntry(model, B, Lq, dtype, training, params, needs, ids.device)
+        rt.ensure_shadows(ent.shadow_groups)
         saved = torch.empty(ent.saved_bytes, dtype=torch.uint8, device=ids.device)
         ws = rt.workspace(ent.ws_bytes, ids.device)
         seed = (rt.next_seed() * 64) & 0xFFFFFFFFFFFFFFFF if training else 0

@@ -168,3 +168,84 @@ def test_bert_weight_gradients_transposed_operands_equal_row_major():
             continue                      # analytically zero gradient: rounding noise on both sides
         err = (a - b).norm().item() / max(b.norm().item(), 1e-12)
         assert err <= 1e-5, f"{k}: transposed-operand gradient differs from the row-major one by {err:.3e}"
+
+
+def test_weight_shadows_follow_every_kind_of_parameter_update(tmp_path):
+    """bf16 weight shadows (hamspine.rt.ensure_shadows, HAMSPINE_WEIGHT_SHADOWS=1; off by default -- measured neutral): the
+    towers read persistent bf16 copies instead of casting every weight in every forward.  A training run with them is
+    bit-identical to one without, the fused AdamW step keeps them current without casts, and anything else that touches a
+    parameter -- an in-place torch op, load_state_dict, FusedSGD -- is picked up by the next forward."""
+    import model as product_model
+    from hamspine import functional as F
+    from hamspine.optim import FusedAdamW, FusedSGD
+    name = "e2e_basic_mlp"
+    seed, kw = gc.E2E_CASES[name]
+    images, ids, mask, labels, tab = gc.e2e_inputs(kw)
+    d = gc.save_bert_dir(gc.TINY_BERT, str(tmp_path / "bert"))
+    hamspine.set_compute_dtype("bf16")
+
+    def build():
+        m = product_model.MultimodalBaselineModel(pretrained_image=False, image_weights_path=None, text_model_name=d,
+                                                  **gc.E2E_COMMON, **kw)
+        return load_procedural(m, seed).to(DEV).train()
+
+    def run(m, opt, steps):
+        out = []
+        for _ in range(steps):
+            opt.zero_grad(set_to_none=True)
+            logits = gc.e2e_forward(m, name, kw, images.to(DEV), ids.to(DEV), mask.to(DEV), tab.to(DEV))
+            loss = F.cross_entropy(logits, labels.to(DEV), label_smoothing=0.02)
+            loss.backward()
+            opt.step()
+            out.append(loss.item())
+        return out
+
+    from hamspine.nn.bert import BertModel
+    rt.clear_shadows()
+    m0 = build()
+    l0 = run(m0, FusedAdamW(m0.parameters(), lr=1e-3, weight_decay=0.01), 3)     # default: no shadows
+    assert not rt._shadows
+    os.environ["HAMSPINE_WEIGHT_SHADOWS"] = "1"
+    try:
+        _shadow_checks(build, run, m0, l0, BertModel, name, kw, images, ids, mask, tab)
+    finally:
+        os.environ.pop("HAMSPINE_WEIGHT_SHADOWS", None)
+        rt.clear_shadows()
+
+
+def _shadow_checks(build, run, m0, l0, BertModel, name, kw, images, ids, mask, tab):
+    from hamspine.optim import FusedAdamW, FusedSGD
+    m1 = build()
+    opt1 = FusedAdamW(m1.parameters(), lr=1e-3, weight_decay=0.01)
+    l1 = run(m1, opt1, 3)
+    w = m1.image_encoder.model.layer1[0].conv1.weight
+    bert = next(mod for mod in m1.text_encoder.modules() if isinstance(mod, BertModel))
+    qw = bert.encoder.layer[0].attention.self.query.weight
+    assert rt.shadow_ptr_of(w) is not None and rt.shadow_ptr_of(qw) is not None, "the towers registered no shadows"
+    assert l0 == l1, (l0, l1)
+    for (k, a), (_, b) in zip(m0.state_dict().items(), m1.state_dict().items()):
+        assert torch.equal(a, b), k
+
+    def shadow_equals_weight(p):
+        rec = rt._shadows[id(p)]
+        return torch.equal(rec.view.cpu(), p.detach().reshape(-1).to(torch.bfloat16).cpu()
+                           if p.dim() != 4 else p.detach().permute(0, 2, 3, 1).reshape(-1).to(torch.bfloat16).cpu())
+    torch.cuda.synchronize()
+    assert shadow_equals_weight(w) and shadow_equals_weight(qw), "AdamW did not keep the shadows current"
+    # an in-place torch op: picked up through _version by the next forward
+    with torch.no_grad():
+        w.mul_(0.5)
+    assert not shadow_equals_weight(w)
+    gc.e2e_forward(m1, name, kw, images.to(DEV), ids.to(DEV), mask.to(DEV), tab.to(DEV))
+    torch.cuda.synchronize()
+    assert shadow_equals_weight(w)
+    # load_state_dict
+    m1.load_state_dict(m0.state_dict())
+    gc.e2e_forward(m1, name, kw, images.to(DEV), ids.to(DEV), mask.to(DEV), tab.to(DEV))
+    torch.cuda.synchronize()
+    assert shadow_equals_weight(w) and shadow_equals_weight(qw)
+    # a raw-pointer writer that does not write shadows
+    run(m1, FusedSGD(m1.parameters(), lr=1e-2), 1)
+    gc.e2e_forward(m1, name, kw, images.to(DEV), ids.to(DEV), mask.to(DEV), tab.to(DEV))
+    torch.cuda.synchronize()
+    assert shadow_equals_weight(w) and shadow_equals_weight(qw)
