@@ -159,7 +159,7 @@ def roofline_by_class(path, steps):
             name = shape_class(combo, M, N, K, R)
             if combo >= 6:                            # grouped weight gradients of the image tower: M problems in one grid
                 nbytes = float(r[12])
-                name = "pointwise_wgrad_grouped" if combo == 6 else "conv_wgrad_grouped"
+                name = {6: "pointwise_wgrad_grouped", 7: "conv_wgrad_grouped", 8: "bert_wgrad_grouped"}[combo]
             bound = "mfma" if flop / nbytes >= RIDGE_FLOP_PER_BYTE else "hbm"
             a = agg.setdefault((name, bound), {"launches": 0, "ms": 0.0, "flop": 0.0, "bytes": 0.0})
             a["launches"] += 1

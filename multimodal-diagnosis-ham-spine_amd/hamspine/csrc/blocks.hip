@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void gather3_kernel(const float* __restrict__ 
 int gemm_impl(const hs_gemm_params* p, hipStream_t stream);
 int gemm_stat_rows(const hs_gemm_params* p);
 struct GemmGroup;
-GemmGroup* gemm_group_open(hipStream_t s, int slot);
+GemmGroup* gemm_group_open(hipStream_t s, long long slot);   // slot: any key that is stable across steps (its device table is cached)
 int gemm_group_add(GemmGroup* g, const hs_gemm_params* p, hipStream_t s);
 int gemm_group_flush(GemmGroup* g, hipStream_t s);
 int attention_bwd_fused(const hs_attn_desc& d, const void* q, const void* k, const void* v, const void* dO, void* dq, void* dk,
@@ -64,6 +64,10 @@ struct Run {
     // chain is done (their operands -- saved activations and the ws gradients, which are then not released -- stay alive)
     bool defer_wgrad = false;
     GemmGroup *grp_pw = nullptr, *grp_conv = nullptr;
+    // BertLayer backward: the layer's four K-contiguous weight-gradient GEMMs are collected and run as ONE grouped grid at the
+    // end of the layer (group_nt is set in plan mode too: it decides what scratch the layer needs)
+    bool group_nt = false;
+    GemmGroup* grp_nt = nullptr;
 };
 
 // one non-blocking side stream and a ring of events per device (events are re-recordable; every composite joins
@@ -460,6 +464,14 @@ static bool wgrad_nt_enabled() {             // off: weight gradients from the r
     }
     return g_wgrad_nt == 1;
 }
+static bool grouped_bert_wgrad_enabled() {   // HAMSPINE_GROUPED_BERT_WGRAD=0: every weight-gradient GEMM of a BertLayer on its own
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("HAMSPINE_GROUPED_BERT_WGRAD");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
 static bool dgrad_nt_enabled() {          // HAMSPINE_DGRAD_NT=0: BERT data gradients read the row-contiguous weights
     static int v = -1;
     if (v < 0) {
@@ -488,12 +500,16 @@ static int linear_wgrad_nt_run(Run& r, const void* xT, const void* dyT, long lon
         p.D_seg[0] = dw_seg[0];
         p.D_seg[1] = dw_seg[1];
     }
-    if (db && hs_gemm_suggest_split(out_f, in_f, (int)M, r.dt) <= 1 && fused_bias_grad_enabled()) {
+    if (db && (r.group_nt || hs_gemm_suggest_split(out_f, in_f, (int)M, r.dt) <= 1) && fused_bias_grad_enabled()) {
         p.rowsum_a = db;
         if (seg_rows > 0) {
             p.rowsum_seg[0] = db_seg[0];
             p.rowsum_seg[1] = db_seg[1];
         }
+    }
+    if (r.group_nt) {                    // no split-K inside a grouped grid: the group fills the chip
+        if (!r.plan && !(knock() & 2)) HS_PROPAGATE(gemm_group_add(r.grp_nt, &p, r.s));
+        return HS_OK;
     }
     if (!r.plan && (knock() & 2)) { const int sp = hs_gemm_suggest_split(p.M, p.N, p.K, p.dtype); p.split_k = sp; if (sp > 1) (void)r.ws.alloc(hs_gemm_splitk_ws_bytes(&p)); return HS_OK; }
     return gemm_splitk(r, p);
@@ -1183,7 +1199,17 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
     }
     // bf16: weight gradients from transposed operands (see linear_wgrad_nt_run); tbuf holds the two transposes of one layer
     const bool nt = r.dt == HS_BF16 && wgrad_nt_enabled() && M % 8 == 0 && Hd % 8 == 0 && I % 8 == 0;
-    char* tA = nt ? (char*)r.ws.alloc(M * (long long)std::max(3 * Hd, I) * 2) : nullptr;   // dY^T (one at a time)
+    // grouped: the four GEMMs run together at the end of the layer, so each keeps its own dY^T
+    const bool grouped = nt && grouped_bert_wgrad_enabled() && !overlap_enabled();
+    char* tA = nt ? (char*)r.ws.alloc(M * (long long)std::max(3 * Hd, I) * 2) : nullptr;   // dY^T (one at a time; grouped: FFN1's)
+    char* tA_ffn2 = grouped ? (char*)r.ws.alloc(M * (long long)Hd * 2) : tA;
+    char* tA_ao = grouped ? (char*)r.ws.alloc(M * (long long)Hd * 2) : tA;
+    char* tA_qkv = grouped ? (char*)r.ws.alloc(M * 3ll * Hd * 2) : tA;
+    r.group_nt = grouped;
+    if (grouped && !r.plan) {
+        r.grp_nt = gemm_group_open(r.s, (long long)(uintptr_t)d.q.dw);      // one cached problem table per layer (keyed by its dWq)
+        HS_REQUIRE(r.grp_nt != nullptr, "bert_layer_bwd: cannot set up the grouped weight-gradient launch");
+    }
     // X^T of the four saved activations the weight gradients read: all known when the layer's backward starts, so they are
     // transposed by ONE launch (together with the weight copies below) instead of one launch in front of each GEMM
     char* tX_g = nt ? (char*)r.ws.alloc(M * (long long)I * 2) : nullptr;
@@ -1196,11 +1222,17 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
         only_b.dw = nullptr;
         return linear_wgrad_run(r, nullptr, M, 0, only_b, dy_rm, ldy);
     };
-    auto wgrad = [&](const void* x_rm, const void* xT, int in_f, const hs_linear& lin, const void* dy_rm, int ldy) -> int {
-        if (!nt || !lin.dw) return linear_wgrad_run(r, x_rm, M, in_f, lin, dy_rm, ldy);
-        HS_PROPAGATE(transpose_run(r, dy_rm, tA, M, lin.out_f, ldy));
-        const bool fused_b = lin.db && hs_gemm_suggest_split(lin.out_f, in_f, (int)M, r.dt) <= 1 && fused_bias_grad_enabled();
-        HS_PROPAGATE(linear_wgrad_nt_run(r, xT, tA, M, in_f, lin.out_f, lin.dw, lin.db, 0, nullptr, nullptr));
+    auto wgrad = [&](const void* x_rm, const void* xT, int in_f, const hs_linear& lin, const void* dy_rm, int ldy, char* tAk) -> int {
+        if (!nt || !lin.dw) {
+            const bool keep = r.group_nt;
+            r.group_nt = false;                                  // (bias-only / f32 paths are not grouped)
+            const int st = linear_wgrad_run(r, x_rm, M, in_f, lin, dy_rm, ldy);
+            r.group_nt = keep;
+            return st;
+        }
+        HS_PROPAGATE(transpose_run(r, dy_rm, tAk, M, lin.out_f, ldy));
+        const bool fused_b = lin.db && (r.group_nt || hs_gemm_suggest_split(lin.out_f, in_f, (int)M, r.dt) <= 1) && fused_bias_grad_enabled();
+        HS_PROPAGATE(linear_wgrad_nt_run(r, xT, tAk, M, in_f, lin.out_f, lin.dw, lin.db, 0, nullptr, nullptr));
         if (lin.db && !fused_b) HS_PROPAGATE(bias_by_colsum(lin, dy_rm, ldy));
         return HS_OK;
     };
@@ -1232,9 +1264,9 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
         }
         if (n > 0) CALLK(r, 4, hs_transpose_bf16_multi(n, src, dst, R, Cc, lds, ldd, r.s));
     }
-    HS_PROPAGATE(on_side(r, [&]() { return wgrad(L.g, tX_g, I, out_l_w, g2, Hd); }));
+    HS_PROPAGATE(on_side(r, [&]() { return wgrad(L.g, tX_g, I, out_l_w, g2, Hd, tA_ffn2); }));
     HS_PROPAGATE(linear_dgrad_run(r, d.out_l, L.wo, g2, M, Hd, du, I, r.dt, HS_MUL_GELU_GRAD, L.u, I, nullptr, wo_t));
-    HS_PROPAGATE(on_side(r, [&]() { return wgrad(L.x1, tX_x1, Hd, d.inter_l, du, I); }));
+    HS_PROPAGATE(on_side(r, [&]() { return wgrad(L.x1, tX_x1, Hd, d.inter_l, du, I, tA); }));
     // dx1 = du Wi + dh2 (residual into x1)
     HS_PROPAGATE(linear_dgrad_run(r, d.inter_l, L.wi, du, M, I, dx1, Hd, r.dt, HS_MUL_NONE, nullptr, 0, dh2, wi_t));
     // ---- attention output LN + dense ----
@@ -1251,7 +1283,7 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
                                  d.ln1.dbeta ? d.ln1.dbeta : (scratch ? scratch + Hd : nullptr), ln_ws, ln_ws_bytes, M, Hd, r.s));
         if (d.hidden_dropout > 0.f) CALL(r, hs_dropout(r.dt, dh1, dd1, M * Hd, d.hidden_dropout, d.seed * 8 + 2, r.s));
     }
-    HS_PROPAGATE(on_side(r, [&]() { return wgrad(L.ctx, tX_ctx, Hd, ao_w, g1, Hd); }));
+    HS_PROPAGATE(on_side(r, [&]() { return wgrad(L.ctx, tX_ctx, Hd, ao_w, g1, Hd, tA_ao); }));
     HS_PROPAGATE(linear_dgrad_run(r, d.ao, L.wao, g1, M, Hd, dctx, Hd, r.dt, HS_MUL_NONE, nullptr, 0, nullptr));
     // ---- attention core ----
     const char* qkv = (const char*)L.qkv;
@@ -1263,12 +1295,12 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
         // one GEMM for the three weight gradients: [dWq; dWk; dWv] = dqkv^T x, rows routed to the three tensors
         const bool fused = d.q.dw && d.k.dw && d.v.dw;
         if (fused && nt) {
-            HS_PROPAGATE(transpose_run(r, dqkv, tA, M, 3 * Hd, 3 * Hd));
-            const bool bias_too = d.q.db && d.k.db && d.v.db && hs_gemm_suggest_split(3 * Hd, Hd, (int)M, r.dt) <= 1 &&
+            HS_PROPAGATE(transpose_run(r, dqkv, tA_qkv, M, 3 * Hd, 3 * Hd));
+            const bool bias_too = d.q.db && d.k.db && d.v.db && (r.group_nt || hs_gemm_suggest_split(3 * Hd, Hd, (int)M, r.dt) <= 1) &&
                                   fused_bias_grad_enabled();
             float* dws[2] = {d.k.dw, d.v.dw};
             float* dbs[2] = {d.k.db, d.v.db};
-            HS_PROPAGATE(linear_wgrad_nt_run(r, tX_x, tA, M, Hd, 3 * Hd, d.q.dw, bias_too ? d.q.db : nullptr, Hd, dws, dbs));
+            HS_PROPAGATE(linear_wgrad_nt_run(r, tX_x, tA_qkv, M, Hd, 3 * Hd, d.q.dw, bias_too ? d.q.db : nullptr, Hd, dws, dbs));
             if (bias_too) return HS_OK;
             const hs_linear* lins[3] = {&d.q, &d.k, &d.v};
             for (int i = 0; i < 3; ++i) HS_PROPAGATE(bias_by_colsum(*lins[i], dq ? dq + (long long)i * Hd * es : nullptr, 3 * Hd));
@@ -1310,6 +1342,8 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
         // dx = dqkv Wqkv + dh1 (residual of the attention-output LN input)
         HS_PROPAGATE(linear_dgrad_run(r, qkv_lin, L.wqkv, dqkv, M, 3 * Hd, dx, Hd, r.dt, HS_MUL_NONE, nullptr, 0, dh1, wqkv_t));
     }
+    if (r.group_nt && !r.plan) HS_PROPAGATE(gemm_group_flush(r.grp_nt, r.s));
+    r.group_nt = false;
     HS_PROPAGATE(side_join(r));
     RUN_CHECK_ARENAS(r, "bert_layer_bwd");
     return HS_OK;

@@ -138,7 +138,7 @@ struct Prepared {
     dim3 grid;
     double flops;
 };
-static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q) {
+static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q, int force_cfg = -1) {
     HS_REQUIRE(p != nullptr, "hs_gemm: null params");
     HS_REQUIRE(p->dtype == HS_F32 || p->dtype == HS_BF16, "hs_gemm: bad dtype %d", p->dtype);
     HS_REQUIRE(p->M > 0 && p->N > 0 && p->K >= 0, "hs_gemm: bad dims %d %d %d", p->M, p->N, p->K);
@@ -299,6 +299,7 @@ static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q
     // intensity: 128x128 never wins, 128x64 wins once it yields >= ~1500 tiles, otherwise 64x64.
     if (cfg < 0) cfg = auto_cfg(p, vec);
     if (p->rowsum_a && p->a_kind == HS_A_KC && cfg != CFG_128x64 && cfg != CFG_64x64) cfg = CFG_128x64;   // instantiated tiles of the RS variant
+    if (force_cfg >= 0) cfg = force_cfg;                       // grouped launches: the group's tile
     if (g_dbg_cfg >= 0 && g_dbg_cfg <= CFG_64x64 && cfg != CFG_STEM) cfg = g_dbg_cfg;
     if (g_dbg_cfg >= CFG_256x128 && g_dbg_cfg <= CFG_256x128x32 && bf16 && !conv) cfg = g_dbg_cfg;
     if (cfg == CFG_128x128x32 && split > 1) cfg = CFG_128x128;      // the three-workgroups-per-CU kernel has no split-K code
@@ -448,7 +449,7 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
 // a training step adds the same problems with the same pointers every time, so the table is uploaded once.
 // ------------------------------------------------------------------------------------------------
 struct GemmGroup {
-    int combo = -1;
+    int combo = -1;       // 2 / 5: 64x64 tiles (gemm_bf16_grouped_kernel); 0: K-contiguous operands, 256x128 tiles, row sums (_big_kernel)
     std::vector<GemmArgs> items;
     std::vector<int> first;
     int total = 0, ticket_off = 0;
@@ -458,9 +459,9 @@ struct GemmGroup {
     std::vector<char> shadow;      // what the device table holds
 };
 static constexpr int kGroupMax = 64;
-GemmGroup* gemm_group_open(hipStream_t s, int slot) {
+GemmGroup* gemm_group_open(hipStream_t s, long long slot) {
     static std::mutex mu;
-    static std::map<std::tuple<int, hipStream_t, int>, GemmGroup*> groups;
+    static std::map<std::tuple<int, hipStream_t, long long>, GemmGroup*> groups;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
@@ -505,10 +506,12 @@ int gemm_group_flush(GemmGroup* g, hipStream_t s) {
     }
     ProfRec rec;
     const bool timed = prof_begin(s, g->flops, g->combo == 5 ? 1 : 0, rec);
-    const int st = g->combo == 5 ? launch_bf16_grouped_conv(5, (const GemmArgs*)(g->dev + kHead), (const int*)g->dev, n, g->total, s)
-                                 : launch_bf16_grouped_plain(2, (const GemmArgs*)(g->dev + kHead), (const int*)g->dev, n, g->total, s);
+    const int st = g->combo == 5   ? launch_bf16_grouped_conv(5, (const GemmArgs*)(g->dev + kHead), (const int*)g->dev, n, g->total, s)
+                   : g->combo == 0 ? launch_bf16_grouped_big(0, (const GemmArgs*)(g->dev + kHead), (const int*)g->dev, n, g->total, s)
+                                   : launch_bf16_grouped_plain(2, (const GemmArgs*)(g->dev + kHead), (const int*)g->dev, n, g->total, s);
     if (timed) {
-        rec.M = n; rec.N = 0; rec.K = 0; rec.combo = g->combo == 5 ? 7 : 6; rec.cfg = CFG_64x64; rec.split = 0; rec.batch = 1;
+        rec.M = n; rec.N = 0; rec.K = 0; rec.combo = g->combo == 5 ? 7 : g->combo == 0 ? 8 : 6;
+        rec.cfg = g->combo == 0 ? CFG_256x128 : CFG_64x64; rec.split = 0; rec.batch = 1;
         rec.conv_r = 0; rec.conv_stride = 0;
         rec.bytes = g->bytes;
         prof_end(s, rec);
@@ -525,9 +528,11 @@ int gemm_group_flush(GemmGroup* g, hipStream_t s) {
 int gemm_group_add(GemmGroup* g, const hs_gemm_params* p, hipStream_t s) {
     if (!g) return gemm_impl(p, s);
     Prepared q;
-    HS_PROPAGATE(gemm_prepare(p, s, q));
-    const bool ok = q.bf16 && q.cfg == CFG_64x64 && (q.combo == 2 || q.combo == 5) && q.batch == 1 && !q.a.stamps &&
-                    (q.split == 1 || q.a.tickets != nullptr) && !q.a.rowsum[0] && !q.a.colstats;
+    const bool big = p->a_kind == HS_A_KC && p->b_kind == HS_B_KC;       // K-contiguous weight gradients: 256x128 tiles
+    HS_PROPAGATE(gemm_prepare(p, s, q, big ? CFG_256x128 : -1));
+    const bool ok = big ? (q.bf16 && q.cfg == CFG_256x128 && q.combo == 0 && q.batch == 1 && q.split == 1 && !q.a.stamps && !q.a.colstats)
+                        : (q.bf16 && q.cfg == CFG_64x64 && (q.combo == 2 || q.combo == 5) && q.batch == 1 && !q.a.stamps &&
+                           (q.split == 1 || q.a.tickets != nullptr) && !q.a.rowsum[0] && !q.a.colstats);
     if (!ok) return gemm_impl(p, s);
     const long long ngroups = q.split > 1 ? (q.split + kSplitGroup - 1) / kSplitGroup : 0;
     const long long need = q.split > 1 ? (long long)q.a.tiles_m * q.a.tiles_n * (1 + (ngroups > 1 ? ngroups : 0)) : 0;
@@ -608,7 +613,7 @@ hs_status hs_prof_calibrate(void* stream, int32_t n, float* avg_us) {
     *avg_us = (float)(tot / n * 1e3);
     return HS_OK;
 }
-/* Synchronises, appends one CSV line per recorded launch (cls,combo,cfg,M,N,K,batch,split,R,stride,ms,flops,bytes; a grouped launch: combo 6 / 7 = grouped tn / conv weight gradients, M = problems in it) to `path`, clears. */
+/* Synchronises, appends one CSV line per recorded launch (cls,combo,cfg,M,N,K,batch,split,R,stride,ms,flops,bytes; a grouped launch: combo 6 / 7 / 8 = grouped tn / conv / nt weight gradients, M = problems in it) to `path`, clears. */
 hs_status hs_prof_dump(const char* path) {
     HS_CHECK_HIP(hipDeviceSynchronize());
     std::lock_guard<std::mutex> lk(hs::g_prof_mu);

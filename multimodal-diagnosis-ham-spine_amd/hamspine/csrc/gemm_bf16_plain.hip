@@ -56,4 +56,16 @@ int launch_bf16_grouped_plain(int combo, const GemmArgs* list, const int* first_
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
+int launch_bf16_grouped_big(int combo, const GemmArgs* list, const int* first_wg, int n, int total_wgs, hipStream_t s) {
+    if (combo != 0) {
+        set_error("launch_bf16_grouped_big: only K-contiguous operands (combo %d)", combo);
+        return HS_ERR_ARG;
+    }
+    auto kernel = gemm_bf16_grouped_big_kernel<HS_A_KC, HS_B_KC>;
+    constexpr int lds = 3 * 384 * 64 * 2;
+    if (lds_attr_needed((const void*)kernel)) HS_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kernel, dim3(total_wgs), dim3(512), lds, s, list, first_wg, n);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
 }  // namespace hs

@@ -1218,6 +1218,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_grouped_kernel(const GemmArgs* 
     gemm_bf16_body<64, 64, 64, AK, BKIND, true>(a, local - bz * tiles, bz);
 }
 
+// Grouped K-contiguous weight gradients (the four Linear layers of a BertLayer: dW = dY^T X on transposed operands, K = the
+// 4096 tokens): alone each is 72-288 tiles on a chip with 256-768 slots (430 TFLOP/s); together, as 256x128 tiles with the
+// bias gradients as row sums and no split-K code, they fill it (one GEMM of their combined size measured 611 TFLOP/s).
+template <int AK, int BKIND>
+__global__ __launch_bounds__(512) void gemm_bf16_grouped_big_kernel(const GemmArgs* __restrict__ list, const int* __restrict__ first_wg, int n) {
+    const int bid = blockIdx.x, lane = threadIdx.x & 63;
+    const int lo = lane < n ? first_wg[lane] : 0x7fffffff;
+    const int p = __builtin_amdgcn_readfirstlane(__popcll(__ballot(lo <= bid)) - 1);
+    const int local = bid - __builtin_amdgcn_readfirstlane(first_wg[p]);
+    gemm_bf16_body<256, 128, 64, AK, BKIND, true, 4, true, 3, false>(list[p], local, 0);
+}
+
 // ================================================================================================
 // exact-f32 kernel (v_mfma_f32_32x32x2_f32); BK = 32
 // ================================================================================================

@@ -65,6 +65,10 @@ def main():
         shapes = [("tn", 256, 64, 100352), ("tn", 64, 256, 100352), ("tn", 128, 256, 100352), ("tn", 512, 128, 25088),
                   ("tn", 128, 512, 25088), ("tn", 1024, 256, 6272), ("tn", 256, 1024, 6272), ("tn", 2048, 512, 1568)]
         splits = (1, 4, 8, 16, 32, 64, 128, 256)
+    if "--fill" in sys.argv:              # does a K = 4096 weight-gradient GEMM get faster per FLOP when the grid fills the chip?
+        shapes = [("nt", 3072, 768, 4096), ("nt", 6912, 768, 4096), ("nt", 12288, 768, 4096), ("nt", 768, 3072, 4096),
+                  ("nt", 2304, 768, 4096), ("nt", 768, 768, 4096)]
+        splits = (1, 4)
     only = [a for a in sys.argv[1:] if a in ("nt", "nn", "tn")]
     for kind, M, N, K in shapes:
         if only and kind not in only:

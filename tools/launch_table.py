@@ -4,7 +4,7 @@ import collections
 import csv
 import sys
 
-COMBO = ["nt", "nn", "tn", "conv", "dgrad", "wgrad", "tn-grp", "wg-grp"]
+COMBO = ["nt", "nn", "tn", "conv", "dgrad", "wgrad", "tn-grp", "wg-grp", "nt-grp"]
 CFG = {0: "128x128", 1: "128x64", 2: "64x64", 3: "stem", 4: "256x128", 5: "128x128k32", 6: "256x128k32"}
 
 
