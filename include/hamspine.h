@@ -302,6 +302,12 @@ hs_status hs_adam_step_multi_shadow(int32_t count, float* const* params, const f
                                     float* const* exp_avg_sq, void* const* bf16_shadow, const int64_t* n, float lr, float beta1,
                                     float beta2, float eps, float weight_decay, int32_t step, int32_t decoupled,
                                     float grad_scale, void* stream);
+/* Caller-scoped grouping of weight-gradient GEMMs: between _begin and _end, the K-contiguous ("nt") weight-gradient GEMMs
+   that hs_linear_bwd issues on `stream` are collected and then launched as ONE grid (an MLP's two Linear layers fill the chip
+   together where each alone does not).  The workspaces passed to the collected hs_linear_bwd calls must stay alive and must
+   not overlap until _end returns.  No reference counterpart (cuBLAS launches every GEMM on its own). */
+hs_status hs_wgrad_group_begin(void* stream);
+hs_status hs_wgrad_group_end(void* stream);
 /* bf16 shadow registry: while registered, every composite / tower reads `bf16` (n elements of the weight, same memory order)
    instead of casting `w` in its forward.  The caller keeps it equal to bf16(w).  bf16 = NULL forgets the entry.  No
    reference counterpart (torch autocast re-casts weights per call). */

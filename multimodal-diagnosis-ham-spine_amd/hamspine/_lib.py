@@ -207,6 +207,8 @@ def _declare(l):
     l.hs_adam_step_multi.argtypes = [i32, P(vp), P(vp), P(vp), P(vp), P(i64), f32, f32, f32, f32, f32, i32, i32, f32, vp]
     l.hs_adam_step_multi_shadow.argtypes = [i32, P(vp), P(vp), P(vp), P(vp), P(vp), P(i64), f32, f32, f32, f32, f32, i32, i32, f32, vp]
     l.hs_weight_shadow_set.argtypes = [vp, vp]
+    l.hs_wgrad_group_begin.argtypes = [vp]
+    l.hs_wgrad_group_end.argtypes = [vp]
     l.hs_weight_shadow_clear.argtypes = []
     l.hs_weight_shadow_clear.restype = None
     l.hs_sgd_step_multi.argtypes = [i32, P(vp), P(vp), P(vp), P(i64), f32, f32, f32, i32, i32, f32, vp]

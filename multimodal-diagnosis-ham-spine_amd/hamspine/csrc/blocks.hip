@@ -399,6 +399,16 @@ static bool fused_bias_grad_enabled() {     // HAMSPINE_FUSED_BIAS_GRAD=0: bias 
 static bool bias_in_wgrad(int dt, int out_f, int in_f, long long M) {
     return dt == HS_BF16 && fused_bias_grad_enabled() && hs_gemm_suggest_split(out_f, in_f, (int)M, dt) <= 1;
 }
+// Caller-scoped grouping (hs_wgrad_group_begin / _end): between the two calls the K-contiguous weight-gradient GEMMs that
+// hs_linear_bwd issues on that stream are collected and run as one grouped grid at _end (an MLP's two Linear layers: two
+// under-filled launches become one).  The caller keeps the workspaces of the collected calls alive and distinct until _end.
+static std::mutex g_wg_mu;
+static std::unordered_map<hipStream_t, GemmGroup*> g_wg_open;
+static GemmGroup* open_wgrad_group(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_wg_mu);
+    auto it = g_wg_open.find(s);
+    return it == g_wg_open.end() ? nullptr : it->second;
+}
 static bool wgrad_nt_enabled();
 static int linear_wgrad_nt_run(Run& r, const void* xT, const void* dyT, long long M, int in_f, int out_f, float* dw, float* db,
                                int seg_rows, float* const* dw_seg, float* const* db_seg);
@@ -419,14 +429,26 @@ static int linear_wgrad_run(Run& r, const void* x, long long M, int ldx, const h
         const int32_t R[2] = {(int32_t)M, (int32_t)M}, Cc[2] = {lin.out_f, lin.in_f};
         const int64_t lds[2] = {ldy, ldx}, ldd[2] = {M, M};
         CALLK(r, 4, hs_transpose_bf16_multi(2, src, dst, R, Cc, lds, ldd, r.s));
-        const bool fused_b = lin.db && hs_gemm_suggest_split(lin.out_f, lin.in_f, (int)M, r.dt) <= 1 && fused_bias_grad_enabled();
-        HS_PROPAGATE(linear_wgrad_nt_run(r, tB, tA, M, lin.in_f, lin.out_f, lin.dw, lin.db, 0, nullptr, nullptr));
+        GemmGroup* og = r.plan ? nullptr : open_wgrad_group(r.s);
+        const bool keep_flag = r.group_nt;
+        GemmGroup* keep_grp = r.grp_nt;
+        if (og) {
+            r.group_nt = true;
+            r.grp_nt = og;
+        }
+        const bool fused_b = lin.db && (r.group_nt || hs_gemm_suggest_split(lin.out_f, lin.in_f, (int)M, r.dt) <= 1) && fused_bias_grad_enabled();
+        const int st_nt = linear_wgrad_nt_run(r, tB, tA, M, lin.in_f, lin.out_f, lin.dw, lin.db, 0, nullptr, nullptr);
+        r.group_nt = keep_flag;
+        r.grp_nt = keep_grp;
+        HS_PROPAGATE(st_nt);
         if (lin.db && !fused_b) {
             const long long wsb = hs_colsum_ws_bytes(M, lin.out_f);
             void* w = r.ws.alloc(wsb);
             CALL(r, hs_colsum(r.dt, dy, M, lin.out_f, ldy, lin.db, w, wsb, 0, r.s));
         }
-        if (r.plan ? !overlap_enabled() : !r.side) r.ws.release(mk);
+        // the transposed operands stay allocated while a caller-scoped group may still read them (the plan pass cannot know:
+        // it always keeps them, so a plan is never smaller than the run)
+        if (!r.plan && !og && !r.side) r.ws.release(mk);
         return HS_OK;
     }
     if (lin.dw) {
@@ -1200,7 +1222,10 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
     // bf16: weight gradients from transposed operands (see linear_wgrad_nt_run); tbuf holds the two transposes of one layer
     const bool nt = r.dt == HS_BF16 && wgrad_nt_enabled() && M % 8 == 0 && Hd % 8 == 0 && I % 8 == 0;
     // grouped: the four GEMMs run together at the end of the layer, so each keeps its own dY^T
-    const bool grouped = nt && grouped_bert_wgrad_enabled() && !overlap_enabled();
+    // (only when the four outputs give the chip enough 256x128 tiles: BERT-base 216; a narrow model keeps separate launches)
+    const long long big_tiles = (long long)ceil_div(3 * Hd, 256) * ceil_div(Hd, 128) + (long long)ceil_div(Hd, 256) * ceil_div(Hd, 128) +
+                                (long long)ceil_div(I, 256) * ceil_div(Hd, 128) + (long long)ceil_div(Hd, 256) * ceil_div(I, 128);
+    const bool grouped = nt && grouped_bert_wgrad_enabled() && !overlap_enabled() && big_tiles >= 128;
     char* tA = nt ? (char*)r.ws.alloc(M * (long long)std::max(3 * Hd, I) * 2) : nullptr;   // dY^T (one at a time; grouped: FFN1's)
     char* tA_ffn2 = grouped ? (char*)r.ws.alloc(M * (long long)Hd * 2) : tA;
     char* tA_ao = grouped ? (char*)r.ws.alloc(M * (long long)Hd * 2) : tA;
@@ -1771,6 +1796,29 @@ int64_t hs_linear_bwd_ws_bytes(int64_t M, int32_t in_f, int32_t out_f, int32_t d
     return r.ws.peak + 1024;
 }
 
+/* see open_wgrad_group: collect the K-contiguous weight-gradient GEMMs of the hs_linear_bwd calls on `stream` ... */
+hs_status hs_wgrad_group_begin(void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    GemmGroup* g = gemm_group_open(s, -1);
+    HS_REQUIRE(g != nullptr, "wgrad_group_begin: cannot set up the group");
+    std::lock_guard<std::mutex> lk(g_wg_mu);
+    g_wg_open[s] = g;
+    return HS_OK;
+}
+/* ... and launch them as one grouped grid (no-op when nothing was collected) */
+hs_status hs_wgrad_group_end(void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    GemmGroup* g = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_wg_mu);
+        auto it = g_wg_open.find(s);
+        if (it != g_wg_open.end()) {
+            g = it->second;
+            g_wg_open.erase(it);
+        }
+    }
+    return g ? gemm_group_flush(g, s) : HS_OK;
+}
 /* bf16 shadow of an f32 weight (see weight_c): `bf16` = NULL forgets the entry */
 hs_status hs_weight_shadow_set(const float* w, void* bf16) {
     HS_REQUIRE(w != nullptr, "weight_shadow_set: null weight");

@@ -480,6 +480,24 @@ int gemm_group_flush(GemmGroup* g, hipStream_t s) {
     const int n = (int)g->items.size();
     constexpr size_t kHead = 512;                                   // first_wg[0..64] and padding
     const size_t bytes = kHead + (size_t)n * sizeof(GemmArgs);
+    if (g->combo == 0 && n <= 4) {          // small groups of the big-tile kind travel in the kernel arguments
+        ProfRec rec;
+        const bool timed = prof_begin(s, g->flops, 0, rec);
+        const int st = launch_bf16_grouped_big4(g->items.data(), g->first.data(), n, g->total, s);
+        if (timed) {
+            rec.M = n; rec.N = 0; rec.K = 0; rec.combo = 8; rec.cfg = CFG_256x128; rec.split = 0; rec.batch = 1;
+            rec.conv_r = 0; rec.conv_stride = 0;
+            rec.bytes = g->bytes;
+            prof_end(s, rec);
+        }
+        g->combo = -1;
+        g->items.clear();
+        g->first.clear();
+        g->total = 0;
+        g->ticket_off = 0;
+        g->flops = g->bytes = 0;
+        return st;
+    }
     std::vector<char> host(bytes, 0);
     int* fw = (int*)host.data();
     for (int i = 0; i < n; ++i) fw[i] = g->first[i];

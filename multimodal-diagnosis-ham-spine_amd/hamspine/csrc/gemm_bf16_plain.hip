@@ -68,4 +68,24 @@ int launch_bf16_grouped_big(int combo, const GemmArgs* list, const int* first_wg
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
+int launch_bf16_grouped_big4(const GemmArgs* items, const int* first, int n, int total_wgs, hipStream_t s) {
+    if (n < 1 || n > 4) {
+        set_error("launch_bf16_grouped_big4: %d problems (1..4)", n);
+        return HS_ERR_ARG;
+    }
+    GemmArgsPack4 pk;
+    memset(&pk, 0, sizeof(pk));
+    for (int i = 0; i < n; ++i) {
+        pk.a[i] = items[i];
+        pk.first[i] = first[i];
+    }
+    pk.first[n] = total_wgs;
+    pk.n = n;
+    auto kernel = gemm_bf16_grouped_big4_kernel<HS_A_KC, HS_B_KC>;
+    constexpr int lds = 3 * 384 * 64 * 2;
+    if (lds_attr_needed((const void*)kernel)) HS_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kernel, dim3(total_wgs), dim3(512), lds, s, pk);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
 }  // namespace hs

@@ -1230,6 +1230,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_grouped_big_kernel(const GemmAr
     gemm_bf16_body<256, 128, 64, AK, BKIND, true, 4, true, 3, false>(list[p], local, 0);
 }
 
+// the same with up to four problems passed BY VALUE in the kernel arguments (no device-side table to keep current: callers
+// whose operand addresses change every step -- autograd-allocated gradients -- group for free)
+struct GemmArgsPack4 {
+    GemmArgs a[4];
+    int first[5];
+    int n;
+};
+template <int AK, int BKIND>
+__global__ __launch_bounds__(512) void gemm_bf16_grouped_big4_kernel(const GemmArgsPack4 pk) {
+    const int bid = blockIdx.x;
+    int p = 0;
+    for (int i = 1; i < pk.n; ++i) p += bid >= pk.first[i];
+    p = __builtin_amdgcn_readfirstlane(p);
+    gemm_bf16_body<256, 128, 64, AK, BKIND, true, 4, true, 3, false>(pk.a[p], bid - pk.first[p], 0);
+}
+
 // ================================================================================================
 // exact-f32 kernel (v_mfma_f32_32x32x2_f32); BK = 32
 // ================================================================================================

@@ -9,6 +9,7 @@ int launch_bf16_conv(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream
 // one grid for n <= 64 problems of one operand layout, 64x64 tiles (gemm_bf16_grouped_kernel); tables in device memory
 int launch_bf16_grouped_plain(int combo, const GemmArgs* list, const int* first_wg, int n, int total_wgs, hipStream_t s);
 int launch_bf16_grouped_big(int combo, const GemmArgs* list, const int* first_wg, int n, int total_wgs, hipStream_t s);   // 256x128 tiles, nt, row sums
+int launch_bf16_grouped_big4(const GemmArgs* items, const int* first, int n, int total_wgs, hipStream_t s);   // n <= 4, by value
 int launch_bf16_grouped_conv(int combo, const GemmArgs* list, const int* first_wg, int n, int total_wgs, hipStream_t s);
 int launch_f32_plain(int cfg, int combo, bool vec, const GemmArgs& a, dim3 grid, hipStream_t s);
 int launch_f32_conv(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s);

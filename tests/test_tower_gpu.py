@@ -249,3 +249,36 @@ def _shadow_checks(build, run, m0, l0, BertModel, name, kw, images, ids, mask, t
     gc.e2e_forward(m1, name, kw, images.to(DEV), ids.to(DEV), mask.to(DEV), tab.to(DEV))
     torch.cuda.synchronize()
     assert shadow_equals_weight(w) and shadow_equals_weight(qw)
+
+
+def test_grouped_weight_gradients_of_an_mlp_equal_separate_launches():
+    """hs_wgrad_group_begin / _end (the fused MLP node groups its two K-contiguous weight-gradient GEMMs into one grid of
+    256x128 tiles when the outputs are wide enough): same gradients as two Linear nodes (f32 accumulation in both; tile shape
+    and the fused bias row sums change the summation order -> 2e-5 relative), data gradient included."""
+    from hamspine import functional as F
+    hamspine.set_compute_dtype("bf16")
+    g = torch.Generator().manual_seed(11)
+    M, d, hid = 4096, 1024, 4096
+    x = (torch.randn(M, d, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    w1 = (torch.randn(hid, d, generator=g) * 0.03).to(DEV)
+    b1 = (torch.randn(hid, generator=g) * 0.1).to(DEV)
+    w2 = (torch.randn(d, hid, generator=g) * 0.03).to(DEV)
+    b2 = (torch.randn(d, generator=g) * 0.1).to(DEV)
+    cot = torch.randn(M, d, generator=g).to(torch.bfloat16).to(DEV)
+    outs = []
+    for fused in (True, False):
+        ps = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+        xi = x.clone().requires_grad_(True)
+        if fused:
+            y = F.mlp_gelu(xi, *ps)
+        else:
+            y = F.linear(F.linear(xi, ps[0], ps[1], act="gelu"), ps[2], ps[3])
+        (y.float() * cot.float()).sum().backward()
+        torch.cuda.synchronize()
+        outs.append([y.detach().float().cpu(), xi.grad.float().cpu()] + [p.grad.float().cpu() for p in ps])
+    names = ["y", "dx", "dw1", "db1", "dw2", "db2"]
+    for nme, a, b in zip(names, outs[0], outs[1]):
+        # dw2 / db2 read the same operands in both forms (only the summation order differs); everything downstream of the
+        # hidden gradient differs by its bf16 rounding (the fused node rounds gelu' * (dy W2) once, the two nodes twice)
+        tol = 2e-5 if nme in ("dw2", "db2") else 2e-2
+        assert (a - b).abs().max().item() <= tol * b.abs().max().item() + 1e-6, nme
