@@ -188,7 +188,7 @@ typedef struct hs_bn_bwd_params {
     int32_t training;
     int32_t relu;            /* forward fused a ReLU: dz = dy * (y > 0)                          */
     const void* dy;
-    const void* y;           /* forward output (needed when relu)                                */
+    const void* y;           /* forward output (needed when relu, unless scale / shift are given) */
     const void* x;           /* forward input                                                    */
     const float* gamma;
     const float* save_mean;
@@ -199,6 +199,10 @@ typedef struct hs_bn_bwd_params {
     float* dbeta;
     void* ws;
     int64_t ws_bytes;
+    /* optional, relu without a residual input: with y == NULL the ReLU mask is recomputed as fma(x, scale, shift) > 0 from the
+       forward's scale / shift (hs_bn_params.scale / .shift of the same layer): one activation read less in both passes */
+    const float* scale;
+    const float* shift;
 } hs_bn_bwd_params;
 
 hs_status hs_batchnorm_fwd(const hs_bn_params* p, void* stream);

@@ -71,6 +71,7 @@ class BnBwdParams(C.Structure):
         ("dtype", i32), ("C", i32), ("M", i64), ("training", i32), ("relu", i32),
         ("dy", vp), ("y", vp), ("x", vp), ("gamma", vp), ("save_mean", vp), ("save_invstd", vp),
         ("dx", vp), ("dres", vp), ("dgamma", vp), ("dbeta", vp), ("ws", vp), ("ws_bytes", i64),
+        ("scale", vp), ("shift", vp),
     ]
 
 

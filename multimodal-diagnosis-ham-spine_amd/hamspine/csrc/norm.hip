@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         }
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            float v = f[e] * sc[e] + sh[e];
+            float v = fmaf(f[e], sc[e], sh[e]);        // (explicit: the backward recomputes this very value for the ReLU mask)
             if (res) v += r[e];
             if (relu) v = fmaxf(v, 0.f);
             f[e] = v;
@@ -251,19 +251,27 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                              const T* __restrict__ x, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, long long M, int C,
-                                                             int tpc, int relu, float* __restrict__ ws) {
+                                                             int tpc, int relu, float* __restrict__ ws,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift) {
+    // y == nullptr with relu: the forward output was relu(fma(x, scale, shift)) with no residual, so its sign is recomputed
+    // from x (one activation read less; bf16 rounding never turns a positive f32 into 0)
     constexpr int E = Chunk<T>::N;
     const int cg = C / E;
     const int tx = threadIdx.x % tpc, ty = threadIdx.x / tpc, rows_par = 256 / tpc;
     const int cc = blockIdx.x * tpc + tx;
-    float acc[2][E], mu[E], is[E];
+    const bool maskx = relu && y == nullptr;
+    float acc[2][E], mu[E], is[E], sc[E], sf[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) acc[0][e] = acc[1][e] = mu[e] = is[e] = 0.f;
+    for (int e = 0; e < E; ++e) acc[0][e] = acc[1][e] = mu[e] = is[e] = sc[e] = sf[e] = 0.f;
     if (cc < cg) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             mu[e] = mean[cc * E + e];
             is[e] = invstd[cc * E + e];
+            if (maskx) {
+                sc[e] = scale[cc * E + e];
+                sf[e] = shift[cc * E + e];
+            }
         }
         const long long step = (long long)gridDim.y * rows_par;
         long long r = (long long)blockIdx.y * rows_par + ty;
@@ -271,7 +279,14 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
             const long long o = rr * C + (long long)cc * E;
             Chunk<T>::unpack(*(const u32x4*)(dy + o), g);
             Chunk<T>::unpack(*(const u32x4*)(x + o), xv);
-            if (relu) Chunk<T>::unpack(*(const u32x4*)(y + o), yv);
+            if (relu) {
+                if (maskx) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) yv[e] = fmaf(xv[e], sc[e], sf[e]);
+                } else {
+                    Chunk<T>::unpack(*(const u32x4*)(y + o), yv);
+                }
+            }
         };
         auto fold = [&](const float (&g)[E], const float (&xv)[E], const float (&yv)[E]) {
 #pragma unroll
@@ -340,14 +355,23 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                            const T* __restrict__ x, const float* __restrict__ coef,
                                                            T* __restrict__ dx, T* __restrict__ dres, long long nchunks,
-                                                           int cg, int C, int relu) {
+                                                           int cg, int C, int relu, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift) {
     constexpr int E = Chunk<T>::N;
+    const bool maskx = relu && y == nullptr;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long long)gridDim.x * 256) {
         const int c0 = (int)(i % cg) * E;
         float g[E], xv[E], yv[E], o[E], ca[E], cb[E], cc[E], mu[E];
         Chunk<T>::unpack(*(const u32x4*)(dy + i * E), g);
         Chunk<T>::unpack(*(const u32x4*)(x + i * E), xv);
-        if (relu) Chunk<T>::unpack(*(const u32x4*)(y + i * E), yv);
+        if (relu) {
+            if (maskx) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) yv[e] = fmaf(xv[e], scale[c0 + e], shift[c0 + e]);
+            } else {
+                Chunk<T>::unpack(*(const u32x4*)(y + i * E), yv);
+            }
+        }
 #pragma unroll
         for (int e = 0; e < E; e += 4) {
             const f32x4 a = *(const f32x4*)(coef + c0 + e), b = *(const f32x4*)(coef + C + c0 + e),
@@ -418,7 +442,7 @@ static int bn_bwd_t(const hs_bn_bwd_params* p, hipStream_t s) {
     HS_REQUIRE(p->ws && p->ws_bytes >= (long long)g.gy * C * 2 * 4 + 4ll * C * 4, "bn_bwd: workspace too small");
     float* coef = (float*)p->ws + (long long)g.gy * C * 2;
     hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(g.gx, g.gy), dim3(256), 0, s, (const T*)p->dy, (const T*)p->y,
-                       (const T*)p->x, p->save_mean, p->save_invstd, M, C, g.tpc, p->relu, (float*)p->ws);
+                       (const T*)p->x, p->save_mean, p->save_invstd, M, C, g.tpc, p->relu, (float*)p->ws, p->scale, p->shift);
     HS_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, (const float*)p->ws, g.gy, C, p->gamma,
                        p->save_mean, p->save_invstd, 1.f / (float)M, p->training, p->dbeta, p->dgamma, coef);
@@ -427,7 +451,7 @@ static int bn_bwd_t(const hs_bn_bwd_params* p, hipStream_t s) {
         const long long nch = M * C / E;
         const int blocks = (int)std::min<long long>((nch + 255) / 256, 4096);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(blocks), dim3(256), 0, s, (const T*)p->dy, (const T*)p->y,
-                           (const T*)p->x, coef, (T*)p->dx, (T*)p->dres, nch, C / E, C, p->relu);
+                           (const T*)p->x, coef, (T*)p->dx, (T*)p->dres, nch, C / E, C, p->relu, p->scale, p->shift);
         HS_LAUNCH_CHECK();
     }
     return HS_OK;
@@ -439,6 +463,8 @@ int bn_fwd(const hs_bn_params* p, hipStream_t s) {
 }
 int bn_bwd(const hs_bn_bwd_params* p, hipStream_t s) {
     HS_REQUIRE(p && p->dy && p->x && p->dbeta && p->dgamma, "bn_bwd: null argument");
+    HS_REQUIRE(!p->relu || p->y || (p->scale && p->shift && !p->dres),
+               "bn_bwd: a fused ReLU needs the forward output y, or (no residual) the forward's scale / shift to recompute its sign");
     return p->dtype == HS_BF16 ? bn_bwd_t<bf16_t>(p, s) : bn_bwd_t<float>(p, s);
 }
 long long bn_ws_bytes(long long M, int C, int dtype) {

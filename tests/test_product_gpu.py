@@ -914,3 +914,49 @@ def test_kan_update_grid_matches_reference_vectors():
     assert torch.allclose(net.layers[0].grid.cpu(), torch.from_numpy(g2["grid0"]), atol=1e-6)
     assert torch.allclose(net.layers[1].grid.cpu(), torch.from_numpy(g2["grid1"]), atol=1e-5)
     assert torch.allclose(y.cpu(), torch.from_numpy(g2["out"]), atol=2e-4)
+
+
+def test_batchnorm_backward_recomputes_the_relu_mask_from_its_input():
+    """hs_batchnorm_bwd with y = NULL and the forward's scale / shift (optional form, HAMSPINE_BN_MASK_FROM_X=1 in the
+    blocks): the sign of relu(fma(x, scale, shift)) is recomputed from x -- bit-identical gradients to the form that reads
+    the saved forward output, in both numeric modes."""
+    import ctypes as C
+    from hamspine import _lib as L
+    from hamspine import rt
+    lib = L.lib()
+    for dt in (torch.float32, torch.bfloat16):
+        M, Cc = 6272, 256
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(M, Cc, generator=g).to(dt).to(DEV)
+        dy = torch.randn(M, Cc, generator=g).to(dt).to(DEV)
+        gamma = (torch.rand(Cc, generator=g) + 0.5).to(DEV)
+        beta = (torch.randn(Cc, generator=g) * 0.3).to(DEV)
+        y = torch.empty_like(x)
+        mean, invstd, scale, shift = (torch.empty(Cc, device=DEV) for _ in range(4))
+        ws = torch.empty(int(lib.hs_batchnorm_ws_bytes(M, Cc, rt.hs_dtype(dt))), dtype=torch.uint8, device=DEV)
+        p = L.BnParams()
+        p.dtype, p.C, p.M, p.training, p.relu = rt.hs_dtype(dt), Cc, M, 1, 1
+        p.eps, p.momentum = 1e-5, 0.1
+        p.x, p.y, p.gamma, p.beta = x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+        p.save_mean, p.save_invstd, p.scale, p.shift = mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr()
+        p.ws, p.ws_bytes = ws.data_ptr(), ws.numel()
+        L.check(lib.hs_batchnorm_fwd(C.byref(p), rt.stream()), "hs_batchnorm_fwd")
+        outs = []
+        for from_x in (False, True):
+            dx = torch.empty_like(x)
+            dgamma, dbeta = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
+            q = L.BnBwdParams()
+            q.dtype, q.C, q.M, q.training, q.relu = rt.hs_dtype(dt), Cc, M, 1, 1
+            q.dy, q.x, q.gamma = dy.data_ptr(), x.data_ptr(), gamma.data_ptr()
+            q.y = None if from_x else y.data_ptr()
+            q.save_mean, q.save_invstd = mean.data_ptr(), invstd.data_ptr()
+            q.dx, q.dgamma, q.dbeta = dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
+            q.ws, q.ws_bytes = ws.data_ptr(), ws.numel()
+            if from_x:
+                q.scale, q.shift = scale.data_ptr(), shift.data_ptr()
+            L.check(lib.hs_batchnorm_bwd(C.byref(q), rt.stream()), "hs_batchnorm_bwd")
+            torch.cuda.synchronize()
+            outs.append((dx.float().cpu(), dgamma.cpu(), dbeta.cpu()))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        assert (y > 0).float().mean().item() > 0.2          # the ReLU really masks something
