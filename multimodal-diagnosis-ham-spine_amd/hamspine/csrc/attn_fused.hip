@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void attn_fwd_fused_kernel(const AttnFusedArgs
 //   B. dQ  = scale * dS K     (dS from registers, K key-major tile in the permuted key order, as P V in the forward)
 //   C. dV  = Pd^T dO          (Pd through a 32 KiB LDS tile, read back transposed; dO key-major tile)
 //   D. dK  = scale * dS^T Q   (dS through the same LDS tile; Q key-major tile)
-// LDS: V_kc, dO_kc, dO_rc, K_rc, Q_rc (16 KiB each) + the 128x128 bf16 transpose tile = 112 KiB.
+// LDS: V_kc, dO_kc, dO_rc, K_rc, Q_rc (16 KiB each) = 80 KiB; the 128x128 bf16 transpose tile reuses V_kc + dO_kc after phase A.
 // ------------------------------------------------------------------------------------------------------------------
 struct AttnFusedBwdArgs {
     const char *q, *k, *v, *dO;
@@ -235,7 +235,9 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const AttnFusedBwdA
     char* Orc = smem + 2 * TILE;     // dO [q][hd] key-major ("rc") swizzle, contraction over q
     char* Krc = smem + 3 * TILE;     // K  [key][hd] rc swizzle, contraction over keys
     char* Qrc = smem + 4 * TILE;     // Q  [q][hd]  rc swizzle, contraction over q
-    char* PS = smem + 5 * TILE;      // [q][key] bf16, rc swizzle with 128 columns: Pd, then dS
+    char* PS = smem;                 // [q][key] bf16, rc swizzle with 128 columns: Pd, then dS.  ALIASES V_kc + dO_kc, which are
+                                     // dead once phase A's fragments are in registers (barrier below): 80 KiB instead of 112,
+                                     // so two workgroups share a CU and the 384 (batch, head) workgroups run in one round
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -293,6 +295,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const AttnFusedBwdA
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
+    __syncthreads();                                   // every wave has read its V / dO fragments: their tiles become the transpose tile
     // row-wise softmax backward; Pd goes to the transpose tile, dS stays in acc
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -511,7 +514,7 @@ int attention_bwd_fused(const hs_attn_desc& d, const void* q, const void* k, con
         a.seed = d.seed;
     }
     static bool attr_set = false;
-    const int lds = 5 * 128 * 64 * 2 + 128 * 128 * 2;
+    const int lds = 5 * 128 * 64 * 2;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)attn_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -1;
         attr_set = true;
