@@ -122,6 +122,18 @@ typedef struct hs_gemm_params {
        rowsum_seg[i-1] (row index rebased), like D_seg. */
     float* rowsum_a;
     float* rowsum_seg[2];
+    /* optional (bf16 result, batch 1, plain epilogue: no bias / activation / residual / multiplier, alpha = 1; data-gradient
+       layouts): the GEMM result is the gradient of relu(BatchNorm(c)) -- the epilogue also produces that BatchNorm's backward
+       sums per (row tile, channel): bnb_partials[(tile_row * N + n) * 2 + {0, 1}] = sum over the tile's rows of dz and dz * xhat,
+       dz = D * (fma(c, scale, shift) > 0), xhat = (c - mean) * invstd; hs_gemm_tile_rows(p) gives the number of tile rows.
+       hs_bn_bwd_params.partial_rows then skips BatchNorm's own partial-sum pass (reference: the same sums torch's
+       batch_norm_backward takes in its own kernel). */
+    const void* bnb_x;          /* c: [M][N], leading dimension ldd, operand dtype */
+    const float* bnb_scale;
+    const float* bnb_shift;
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    float* bnb_partials;
 } hs_gemm_params;
 
 hs_status hs_gemm(const hs_gemm_params* p, void* stream);
@@ -129,6 +141,8 @@ hs_status hs_gemm(const hs_gemm_params* p, void* stream);
 int64_t hs_gemm_splitk_ws_bytes(const hs_gemm_params* p);
 /* number of row tiles hs_gemm will use for p (rows of a colstats buffer); 0 when p cannot produce colstats. */
 int32_t hs_gemm_stat_rows(const hs_gemm_params* p);
+/* tile rows of the launch hs_gemm makes for p (p->split_k as it will be launched): rows of bnb_partials */
+int32_t hs_gemm_tile_rows(const hs_gemm_params* p);
 /* heuristic split-K factor for a (M,N,K) problem so that the grid fills 256 CUs. */
 int32_t hs_gemm_suggest_split(int32_t M, int32_t N, int32_t K, int32_t dtype);
 /* Optional timing of every GEMM-core launch with HIP events on its stream (measurement only).
@@ -203,6 +217,8 @@ typedef struct hs_bn_bwd_params {
        forward's scale / shift (hs_bn_params.scale / .shift of the same layer): one activation read less in both passes */
     const float* scale;
     const float* shift;
+    /* > 0: ws already holds [partial_rows][C][2] backward sums (hs_gemm_params.bnb_partials): no partial pass is made */
+    int32_t partial_rows;
 } hs_bn_bwd_params;
 
 hs_status hs_batchnorm_fwd(const hs_bn_params* p, void* stream);

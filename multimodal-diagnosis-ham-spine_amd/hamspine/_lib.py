@@ -53,6 +53,7 @@ class GemmParams(C.Structure):
         ("accumulate", i32),
         ("seg_rows", i32), ("D_seg", vp * 2), ("colscale", vp), ("residual_before_act", i32), ("colstats", vp),
         ("rowsum_a", vp), ("rowsum_seg", vp * 2),
+        ("bnb_x", vp), ("bnb_scale", vp), ("bnb_shift", vp), ("bnb_mean", vp), ("bnb_invstd", vp), ("bnb_partials", vp),
     ]
 
 
@@ -71,7 +72,7 @@ class BnBwdParams(C.Structure):
         ("dtype", i32), ("C", i32), ("M", i64), ("training", i32), ("relu", i32),
         ("dy", vp), ("y", vp), ("x", vp), ("gamma", vp), ("save_mean", vp), ("save_invstd", vp),
         ("dx", vp), ("dres", vp), ("dgamma", vp), ("dbeta", vp), ("ws", vp), ("ws_bytes", i64),
-        ("scale", vp), ("shift", vp),
+        ("scale", vp), ("shift", vp), ("partial_rows", i32),
     ]
 
 
@@ -171,6 +172,8 @@ def _declare(l):
     l.hs_gemm_splitk_ws_bytes.argtypes = [P(GemmParams)]
     l.hs_gemm_splitk_ws_bytes.restype = i64
     l.hs_gemm_stat_rows.argtypes = [P(GemmParams)]
+    l.hs_gemm_tile_rows.argtypes = [P(GemmParams)]
+    l.hs_gemm_tile_rows.restype = i32
     l.hs_gemm_suggest_split.argtypes = [i32] * 4
     l.hs_batchnorm_fwd.argtypes = [P(BnParams), vp]
     l.hs_batchnorm_bwd.argtypes = [P(BnBwdParams), vp]

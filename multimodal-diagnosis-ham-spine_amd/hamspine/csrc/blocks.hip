@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void gather3_kernel(const float* __restrict__ 
 
 int gemm_impl(const hs_gemm_params* p, hipStream_t stream);
 int gemm_stat_rows(const hs_gemm_params* p);
+int gemm_tile_rows(const hs_gemm_params* p);
 struct GemmGroup;
 GemmGroup* gemm_group_open(hipStream_t s, long long slot);   // slot: any key that is stable across steps (its device table is cached)
 int gemm_group_add(GemmGroup* g, const hs_gemm_params* p, hipStream_t s);
@@ -671,7 +672,25 @@ static int conv_fwd_run(Run& r, const ConvShape& s, const void* x, const void* w
     CALL(r, gemm_impl(&p, r.s));
     return HS_OK;
 }
-static int conv_dgrad_run(Run& r, const ConvShape& s, const void* dy, const void* w_c, void* dx, const void* residual) {
+// bnb (optional): dx is the gradient of relu(bn(c)) of the PREVIOUS stage -- the GEMM's epilogue also takes that BatchNorm's
+// backward sums (hs_gemm_params.bnb_*); *bnb->rows receives the number of partial rows (0: not produced)
+struct BnSums {
+    const void* c;
+    const float *scale, *shift, *mean, *invstd;
+    float* partials;
+    long long partials_cap;     // bytes available at `partials` (incl. the 4*C coefficient floats behind the sums)
+    int* rows;
+};
+static bool fused_bn_bwd_enabled() {        // HAMSPINE_FUSED_BN_BWD=0: BatchNorm backward makes its own partial-sum pass
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("HAMSPINE_FUSED_BN_BWD");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+static int conv_dgrad_run(Run& r, const ConvShape& s, const void* dy, const void* w_c, void* dx, const void* residual,
+                          const BnSums* bnb = nullptr) {
     hs_gemm_params p = gemm_defaults(r.dt);
     p.M = (int)((long long)s.N * s.H * s.W); p.N = s.Cin; p.K = s.R * s.R * s.Cout;
     p.A = dy; p.B = w_c;
@@ -687,7 +706,19 @@ static int conv_dgrad_run(Run& r, const ConvShape& s, const void* dy, const void
     }
     // late layers: few output tiles under a long K (7x7 maps: 200 tiles x 72 K tiles) -- split-K, reduced inside the launch
     // with the full epilogue (the parity-ordered stride-2 walk has its own K schedule and stays whole)
+    if (bnb && bnb->rows) *bnb->rows = 0;
     if (!r.plan && (knock() & 512)) return HS_OK;
+    if (bnb && !residual && r.dt == HS_BF16 && s.stride == 1 && s.Cin % 4 == 0 && fused_bn_bwd_enabled() && !(knock() & 16)) {
+        p.split_k = hs_gemm_suggest_split(p.M, p.N, p.K, p.dtype);             // what gemm_splitk will choose
+        hs_gemm_params probe = p;
+        probe.bnb_x = bnb->c; probe.bnb_scale = bnb->scale; probe.bnb_shift = bnb->shift; probe.bnb_mean = bnb->mean;
+        probe.bnb_invstd = bnb->invstd; probe.bnb_partials = bnb->partials;
+        const int rows = r.plan ? 0 : gemm_tile_rows(&probe);
+        if (rows > 0 && ((long long)rows * s.Cin * 2 + 4ll * s.Cin) * 4 <= bnb->partials_cap) {
+            p = probe;
+            *bnb->rows = rows;
+        }
+    }
     if (r.dt == HS_BF16 && s.stride == 1) return gemm_splitk(r, p);
     CALL(r, gemm_impl(&p, r.s));
     return HS_OK;
@@ -899,9 +930,10 @@ static int resblock_bwd_run(Run& r, const hs_resblock_desc& d, const void* x, co
     HS_PROPAGATE(side_setup(r));
 
     auto bn_backward = [&](const hs_conv_bn& cb, const StageBuf& b, long long M, const void* g_out, const void* y_out,
-                           int relu, void* g_in_, void* g_res) -> int {
+                           int relu, void* g_in_, void* g_res, int partial_rows = 0) -> int {
         hs_bn_bwd_params q;
         memset(&q, 0, sizeof(q));
+        q.partial_rows = partial_rows;
         q.dtype = r.dt; q.C = cb.Cout; q.M = M;
         q.training = d.training; q.relu = relu;
         q.dy = g_out; q.y = y_out; q.x = b.c;
@@ -937,10 +969,13 @@ static int resblock_bwd_run(Run& r, const hs_resblock_desc& d, const void* x, co
         if (i == 0) {
             if (dx) HS_PROPAGATE(conv_dgrad_run(r, b.s, g_conv[i], b.w_c, dx, dres_for_x));
         } else {
-            HS_PROPAGATE(conv_dgrad_run(r, b.s, g_conv[i], b.w_c, g_in[i], nullptr));
+            // the data gradient of stage i is d relu(bn(c)) of stage i - 1: its GEMM takes that BatchNorm's backward sums along
             const StageBuf& pb = L.main[i - 1];
+            int sum_rows = 0;
+            BnSums bs = {pb.c, pb.scale, pb.shift, pb.mean, pb.invstd, (float*)L.bn_ws, L.bn_ws_bytes, &sum_rows};
+            HS_PROPAGATE(conv_dgrad_run(r, b.s, g_conv[i], b.w_c, g_in[i], nullptr, &bs));
             const long long Mp = (long long)d.N * pb.s.P * pb.s.Q;
-            HS_PROPAGATE(bn_backward(d.main[i - 1], pb, Mp, g_in[i], pb.a, 1, g_conv[i - 1], nullptr));
+            HS_PROPAGATE(bn_backward(d.main[i - 1], pb, Mp, g_in[i], pb.a, 1, g_conv[i - 1], nullptr, sum_rows));
         }
     }
     HS_PROPAGATE(side_join(r));

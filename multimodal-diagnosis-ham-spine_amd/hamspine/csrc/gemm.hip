@@ -191,6 +191,16 @@ static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q
     a.ldm = p->ldm;
     a.accumulate = p->accumulate;
     a.colstats = p->colstats;
+    if (p->bnb_partials) {
+        HS_REQUIRE(bf16 && p->out_dtype == HS_BF16 && batch == 1 && (combo == 1 || combo == 4) && p->bnb_x && p->bnb_scale && p->bnb_shift &&
+                       p->bnb_mean && p->bnb_invstd && !p->bias && !p->colscale && p->act == HS_ACT_NONE && !p->residual && !p->D_preact &&
+                       p->mul_mode == HS_MUL_NONE && p->dropout_p == 0.f && !p->accumulate && p->seg_rows <= 0 && p->alpha == 1.f &&
+                       p->N % 4 == 0 && p->ldd % 4 == 0 && ((((uintptr_t)p->bnb_x) & 7) == 0),
+                   "hs_gemm: bnb_partials needs a bf16 data-gradient GEMM with a plain epilogue (no bias / activation / residual / multiplier)");
+        a.bnb_x = (const char*)p->bnb_x;
+        a.bnb_scale = p->bnb_scale; a.bnb_shift = p->bnb_shift; a.bnb_mean = p->bnb_mean; a.bnb_invstd = p->bnb_invstd;
+        a.bnb_partials = p->bnb_partials;
+    }
     a.colscale = p->colscale;
     a.res_pre_act = p->residual_before_act;
     a.stamps = g_dbg_stamps;
@@ -248,7 +258,7 @@ static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q
                 parity_on = (e && e[0] == '0') ? 0 : 1;
             }
             if (parity_on && bf16 && g.stride == 2 && g.H % 2 == 0 && g.W % 2 == 0 && g.R * g.S <= 15 && split == 1 && batch == 1 &&
-                !p->seg_rows && !p->colstats) {
+                !p->seg_rows && !p->colstats && !p->bnb_partials) {
                 a.parity = 1;
                 a.quarter = g.N * (g.H / 2) * (g.W / 2);
                 a.div_qhw = make_fastdiv((g.H / 2) * (g.W / 2));
@@ -300,6 +310,7 @@ static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q
     if (cfg < 0) cfg = auto_cfg(p, vec);
     if (p->rowsum_a && p->a_kind == HS_A_KC && cfg != CFG_128x64 && cfg != CFG_64x64) cfg = CFG_128x64;   // instantiated tiles of the RS variant
     if (force_cfg >= 0) cfg = force_cfg;                       // grouped launches: the group's tile
+    if (p->bnb_partials && cfg != CFG_64x64 && cfg != CFG_128x64) cfg = CFG_128x64;   // instantiated tiles of the BatchNorm-sum variant
     if (g_dbg_cfg >= 0 && g_dbg_cfg <= CFG_64x64 && cfg != CFG_STEM) cfg = g_dbg_cfg;
     if (g_dbg_cfg >= CFG_256x128 && g_dbg_cfg <= CFG_256x128x32 && bf16 && !conv) cfg = g_dbg_cfg;
     if (cfg == CFG_128x128x32 && split > 1) cfg = CFG_128x128;      // the three-workgroups-per-CU kernel has no split-K code
@@ -386,7 +397,7 @@ static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q
         // (or hs_gemm_debug ablation bit 64).
         static const bool on = [] { const char* e = getenv("HAMSPINE_PERSISTENT"); return e && e[0] == '1'; }();
         static const int cus = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
-        if ((on || (g_dbg_ablate & 64)) && bf16 && split == 1 && batch == 1 && !a.stamps && !p->rowsum_a && (cfg == CFG_64x64 || cfg == CFG_128x64) &&
+        if ((on || (g_dbg_ablate & 64)) && bf16 && split == 1 && batch == 1 && !a.stamps && !p->rowsum_a && !p->bnb_partials && (cfg == CFG_64x64 || cfg == CFG_128x64) &&
             (combo == 0 || combo == 1 || combo == 3 || combo == 4)) {
             const int lds = a.lds_stages * (BM + BN) * 64 * 2;
             const int per_cu = std::max(1, std::min(cfg == CFG_64x64 ? 3 : 2, (160 * 1024) / lds));   // 168 / 256 VGPRs, LDS
@@ -412,6 +423,17 @@ static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q
     q.grid = grid;
     q.flops = flops;
     return HS_OK;
+}
+
+// tile rows of the launch gemm_impl makes for p (a prepare pass without side effects beyond the ticket pool)
+int gemm_tile_rows(const hs_gemm_params* p) {
+    if (!p) return 0;
+    hs_gemm_params c = *p;
+    unsigned char dummy[16];
+    if (c.split_k > 1 && !c.splitk_ws) c.splitk_ws = (float*)dummy;        // prepare only checks that it is there
+    Prepared q;
+    if (gemm_prepare(&c, nullptr, q) != HS_OK) return 0;
+    return q.a.tiles_m;
 }
 
 int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
@@ -659,6 +681,7 @@ int hs_device_ok(void) {
 }
 hs_status hs_gemm(const hs_gemm_params* p, void* stream) { return hs::gemm_impl(p, (hipStream_t)stream); }
 int32_t hs_gemm_stat_rows(const hs_gemm_params* p) { return hs::gemm_stat_rows(p); }
+int32_t hs_gemm_tile_rows(const hs_gemm_params* p) { return hs::gemm_tile_rows(p); }
 int64_t hs_gemm_splitk_ws_bytes(const hs_gemm_params* p) {
     if (!p || p->split_k <= 1) return 0;
     return (int64_t)hs::splitk_slabs(p->split_k) * p->M * p->N * 4;   // slice slabs + the group slabs of the in-launch reduction

@@ -68,6 +68,10 @@ struct GemmArgs {
     int vec_store;             // 1: N%4==0 and all row strides/bases allow 4-wide accesses
     int seg_rows;              // >0: output rows are split over D / D_seg[0] / D_seg[1]
     char* D_seg[2];
+    // optional (BNS kernels): BatchNorm-backward sums of the result, see hs_gemm_params.bnb_*
+    const char* bnb_x;
+    const float *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd;
+    float* bnb_partials;
     float* rowsum[3];          // optional (row-contiguous A): rowsum[seg][m] = sum_k A[k][m], the bias gradient of a wgrad GEMM
     int vec16;                    // bf16 result rows allow 16-byte (8-column) stores: N, ldd, batch strides % 8 == 0, bases 16-byte aligned
     int epi_generic;              // measurement only (hs_gemm_debug bit 32): always take the generic epilogue body
@@ -602,7 +606,9 @@ __device__ __forceinline__ void wait_vm_tiles(int tiles) {       // wait until a
 }
 // SK: the launch may be a split-K one (false: the slab / hand-off code is left out -- its registers count against every launch).
 // PS: persistent-capable (the tile loop and the next-tile prefetch are compiled in; costs registers, so it is a variant).
-template <int BM, int BN, int BK, int AK, int BKIND, bool VEC, int WGM = 2, bool RS = false, int NS = 3, bool SK = true, bool PS = false>
+// BNS: the epilogue can also take the BatchNorm-backward sums of the result (a.bnb_partials; data gradients of ResNet blocks).
+template <int BM, int BN, int BK, int AK, int BKIND, bool VEC, int WGM = 2, bool RS = false, int NS = 3, bool SK = true, bool PS = false,
+          bool BNS = false>
 __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, const int bz) {
     typedef bf16_t T;
     constexpr int ESZ = 2;
@@ -1135,6 +1141,74 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
             ticket = a.tickets + tile_id;
         }
     }
+    // ---- optional: BatchNorm-backward sums of this tile (the result is d relu(bn(c)); plain epilogue, alpha = 1) -----------
+    if constexpr (BNS) {
+        if (a.bnb_partials) {
+            float s1[FN][4], s2[FN][4];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + 4 * g;
+                const bool nok = n < argN;
+                f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc, mu = sc, is = sc;
+                if (nok) {
+                    sc = *(const HS_GLOBAL f32x4*)(a.bnb_scale + n);
+                    sh = *(const HS_GLOBAL f32x4*)(a.bnb_shift + n);
+                    mu = *(const HS_GLOBAL f32x4*)(a.bnb_mean + n);
+                    is = *(const HS_GLOBAL f32x4*)(a.bnb_invstd + n);
+                }
+                float u[4] = {0.f, 0.f, 0.f, 0.f}, w[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int m = m0 + wm * WM + i * 16 + l15;
+                    float cv[4] = {0.f, 0.f, 0.f, 0.f};
+                    const bool live = nok && m < argM;
+                    if (live) load4<T>(a.bnb_x, (long long)m * a.ldd + n, true, 4, cv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gq = (float)(bf16_t)acc[i][j][e];                      // the value the epilogue stores
+                        const float dz = (live && fmaf(cv[e], sc[e], sh[e]) > 0.f) ? gq : 0.f;
+                        u[e] += dz;
+                        w[e] = fmaf(dz, (cv[e] - mu[e]) * is[e], w[e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) {
+                        u[e] += __shfl_xor(u[e], o, 64);
+                        w[e] += __shfl_xor(w[e], o, 64);
+                    }
+                    s1[j][e] = u[e];
+                    s2[j][e] = w[e];
+                }
+            }
+            __syncthreads();                       // every wave is done with the operand ring
+            float* sh2 = (float*)smem;             // [WGM row waves][BN][2]
+            if (l15 == 0) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = wn * WN + j * 16 + 4 * g + e;
+                        sh2[(wm * BN + c) * 2 + 0] = s1[j][e];
+                        sh2[(wm * BN + c) * 2 + 1] = s2[j][e];
+                    }
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < argN) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WGM; ++w) {
+                    t1 += sh2[(w * BN + tid) * 2];
+                    t2 += sh2[(w * BN + tid) * 2 + 1];
+                }
+                float* o = a.bnb_partials + ((long long)tm * argN + n0 + tid) * 2;
+                o[0] = t1;
+                o[1] = t2;
+            }
+            __syncthreads();                       // (persistent variants reuse the ring right after)
+        }
+    }
     // ---- next tile's set-up and first operand slots go out before this tile's epilogue (persistent launches) ----------
     const int em0 = m0, en0 = n0;
     const int nvb = vb + pstride;
@@ -1185,6 +1259,11 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
 template <int BM, int BN, int BK, int AK, int BKIND, bool VEC, int WGM = 2, bool RS = false, int NS = 3>
 __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) {
     gemm_bf16_body<BM, BN, BK, AK, BKIND, VEC, WGM, RS, NS>(a, blockIdx.x, blockIdx.z);
+}
+// data-gradient GEMMs that also take the following BatchNorm's backward sums (a.bnb_partials): 64x64 and 128x64 tiles
+template <int BM, int BN, int AK, int BKIND>
+__global__ __launch_bounds__(256) void gemm_bf16_bns_kernel(const GemmArgs a) {
+    gemm_bf16_body<BM, BN, 64, AK, BKIND, true, 2, false, 3, true, false, true>(a, blockIdx.x, blockIdx.z);
 }
 // persistent-capable variant (64x64 and 128x64 tiles): launched with a.persist = grid size when a GEMM has more tiles than
 // the chip holds at once

@@ -439,11 +439,14 @@ static int bn_bwd_t(const hs_bn_bwd_params* p, hipStream_t s) {
     const long long M = p->M;
     const int C = p->C;
     ColGeom g = col_geom(M, C, E);
+    if (p->partial_rows > 0) g.gy = p->partial_rows;       // the sums came with the data gradient (hs_gemm_params.bnb_partials)
     HS_REQUIRE(p->ws && p->ws_bytes >= (long long)g.gy * C * 2 * 4 + 4ll * C * 4, "bn_bwd: workspace too small");
     float* coef = (float*)p->ws + (long long)g.gy * C * 2;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(g.gx, g.gy), dim3(256), 0, s, (const T*)p->dy, (const T*)p->y,
-                       (const T*)p->x, p->save_mean, p->save_invstd, M, C, g.tpc, p->relu, (float*)p->ws, p->scale, p->shift);
-    HS_LAUNCH_CHECK();
+    if (p->partial_rows <= 0) {
+        hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(g.gx, g.gy), dim3(256), 0, s, (const T*)p->dy, (const T*)p->y,
+                           (const T*)p->x, p->save_mean, p->save_invstd, M, C, g.tpc, p->relu, (float*)p->ws, p->scale, p->shift);
+        HS_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, (const float*)p->ws, g.gy, C, p->gamma,
                        p->save_mean, p->save_invstd, 1.f / (float)M, p->training, p->dbeta, p->dgamma, coef);
     HS_LAUNCH_CHECK();

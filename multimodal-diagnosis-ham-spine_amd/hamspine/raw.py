@@ -48,8 +48,10 @@ def conv_geom(N, H, W, Cin, Kout, R, S, stride, pad, row_pitch=None, img_pitch=N
 def gemm(A, B, D, M, N, K, a_kind=L.A_KC, b_kind=L.B_KC, lda=0, ldb=0, ldd=None, geom=None,
          batch=1, batch_inner=1, a_bs=(0, 0), b_bs=(0, 0), d_bs=(0, 0), split_k=1,
          alpha=1.0, bias=None, act=L.ACT_NONE, preact=None, residual=None, ldr=None,
-         dropout_p=0.0, dropout_seed=0, mul_mode=L.MUL_NONE, mul_src=None, ldm=None, accumulate=False, rowsum_a=None):
-    """D[m][n] = epi(alpha * sum_k A(m,k) B(n,k)); see include/hamspine.h for the operand kinds."""
+         dropout_p=0.0, dropout_seed=0, mul_mode=L.MUL_NONE, mul_src=None, ldm=None, accumulate=False, rowsum_a=None, bnb=None):
+    """D[m][n] = epi(alpha * sum_k A(m,k) B(n,k)); see include/hamspine.h for the operand kinds.
+    bnb = (c, scale, shift, mean, invstd): also return the BatchNorm-backward partial sums of the result
+    (hs_gemm_params.bnb_*) as a float tensor [tile rows][N][2]."""
     need_gpu(A, B, D, bias, preact, residual, mul_src, rowsum_a)
     p = L.GemmParams()
     p.dtype = hs_dtype(A)
@@ -89,8 +91,19 @@ def gemm(A, B, D, M, N, K, a_kind=L.A_KC, b_kind=L.B_KC, lda=0, ldb=0, ldd=None,
     p.ldm = p.ldd if ldm is None else ldm
     p.accumulate = 1 if accumulate else 0
     p.rowsum_a = ptr(rowsum_a)
+    partials = None
+    if bnb is not None:
+        c, sc, sh, mu, inv = bnb
+        need_gpu(c, sc, sh, mu, inv)
+        p.bnb_x, p.bnb_scale, p.bnb_shift, p.bnb_mean, p.bnb_invstd = ptr(c), ptr(sc), ptr(sh), ptr(mu), ptr(inv)
+        p.bnb_partials = 16              # any non-null value: hs_gemm_tile_rows only looks at the configuration
+        rows = int(L.lib().hs_gemm_tile_rows(C.byref(p)))
+        if rows <= 0:
+            raise L.HamspineError("gemm: bnb is not available for this configuration")
+        partials = torch.empty((rows, N, 2), dtype=torch.float32, device=A.device)
+        p.bnb_partials = ptr(partials)
     L.check(L.lib().hs_gemm(C.byref(p), stream_ptr()), "hs_gemm")
-    return D
+    return (D, partials) if bnb is not None else D
 
 
 def suggest_split(M, N, K, dtype):

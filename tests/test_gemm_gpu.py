@@ -321,3 +321,37 @@ def test_persistent_launch_equals_one_tile_per_workgroup(kind, M, N, K):
     for x, y in zip(outs[0], outs[1]):
         assert torch.equal(x, y)
     assert (outs[0][3] - ref.cpu()).abs().max().item() <= 2e-5 * K * 16
+
+
+@pytest.mark.parametrize("M,N,K,split", [(6272, 256, 1024, 1), (1568, 512, 2048, 3), (100352, 64, 256, 1), (1000, 72, 320, 1)])
+def test_data_gradient_gemm_takes_the_batchnorm_backward_sums(M, N, K, split):
+    """hs_gemm_params.bnb_*: a data-gradient GEMM (dx = dy W) whose result is the gradient of relu(bn(c)) also returns that
+    BatchNorm's backward sums per row tile -- sum dz and sum dz * xhat with dz = dx * (fma(c, scale, shift) > 0) taken on the
+    bf16-rounded dx the epilogue stores.  Checked against the same sums of the stored result in float64 (the order of the
+    f32 additions differs: 1e-4 relative to the sum of magnitudes), with and without split-K, ragged tiles included."""
+    g = torch.Generator().manual_seed(M + N)
+    BF = torch.bfloat16
+    dy = (torch.randn(M, K, generator=g) * 0.5).to(BF).to(DEV)
+    W = (torch.randn(K, N, generator=g) * 0.1).to(BF).to(DEV)
+    c = torch.randn(M, N, generator=g).to(BF).to(DEV)
+    gamma = torch.rand(N, generator=g) + 0.5
+    beta = torch.randn(N, generator=g) * 0.3
+    mean, invstd = torch.randn(N, generator=g) * 0.2, torch.rand(N, generator=g) + 0.5
+    scale = (gamma * invstd)
+    shift = beta - mean * scale
+    dev = lambda t: t.float().to(DEV)
+    D = torch.full((M, N), float("nan"), dtype=BF, device=DEV)
+    D, part = raw.gemm(dy, W, D, M, N, K, a_kind=L.A_KC, b_kind=L.B_RC, lda=K, ldb=N, split_k=split,
+                       bnb=(c, dev(scale), dev(shift), dev(mean), dev(invstd)))
+    ref = (dy.float() @ W.float())
+    assert (D.float() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item() + 1e-6
+    cd, dd = c.double().cpu(), D.double().cpu()
+    mask = (torch.addcmul(dev(shift).cpu().float(), c.float().cpu(), dev(scale).cpu().float()) > 0).double()   # f32 fma, as the kernel
+    dz = dd * mask
+    xhat = (cd - mean.float().double()) * invstd.float().double()
+    s = part.double().cpu().sum(0)
+    want1, want2 = dz.sum(0), (dz * xhat).sum(0)
+    tol1 = 1e-4 * dz.abs().sum(0) + 1e-6
+    tol2 = 1e-4 * (dz * xhat).abs().sum(0) + 1e-6
+    assert ((s[:, 0] - want1).abs() <= tol1).all()
+    assert ((s[:, 1] - want2).abs() <= tol2).all()
