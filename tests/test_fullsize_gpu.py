@@ -25,6 +25,7 @@ The bf16 (throughput) mode is then held against the same CPU values with its own
 import contextlib
 import json
 import os
+import re
 
 import pytest
 import torch
@@ -282,3 +283,94 @@ def test_c3_full_size_f32_matches_cpu_oracle(tmp_path):
     assert nograd == sorted(k for k, p in oracle.named_parameters() if k not in g64)
     # DDP(find_unused_parameters=True) semantics (reference mibf_net/train_resnet.py:134): never-used parameters stay None
     assert any(k.startswith("I2Iattention") for k in nograd) and any("pooler" in k for k in nograd)
+
+
+def _tv_key(k):
+    """HF ConvNextModel parameter name -> torchvision `convnext_base().features` name (the product's fallback branch,
+    reference ConNexT/models/ourmodel.py:49-62, holds the same tensors under torchvision's names)."""
+    pre = "image_encoder."
+    if not k.startswith(pre):
+        return k
+    r = k[len(pre):]
+    if r.startswith("layernorm."):
+        return None                         # HF's pooler LayerNorm: `.features` has no such tensor (and the model never uses it)
+    r = r.replace("embeddings.patch_embeddings.", "0.0.").replace("embeddings.layernorm.", "0.1.")
+    m = re.match(r"encoder\.stages\.(\d+)\.downsampling_layer\.(\d)\.(.*)", r)
+    if m:
+        return f"{pre}{2 * int(m.group(1))}.{m.group(2)}.{m.group(3)}"
+    m = re.match(r"encoder\.stages\.(\d+)\.layers\.(\d+)\.(.*)", r)
+    if m:
+        leaf = m.group(3)
+        for a, b in (("layer_scale_parameter", "layer_scale"), ("dwconv.", "block.0."), ("layernorm.", "block.2."),
+                     ("pwconv1.", "block.3."), ("pwconv2.", "block.5.")):
+            if leaf.startswith(a):
+                leaf = b + leaf[len(a):]
+                break
+        return f"{pre}{2 * int(m.group(1)) + 1}.{m.group(2)}.{leaf}"
+    return pre + r
+
+
+def test_c4_full_size_f32_matches_cpu_oracle(tmp_path):
+    """BASELINE configs[3]: ConNeXT (ConvNeXt-base + BERT-base CLS + 1x1-conv cross-attention, reference
+    ConNexT/models/ourmodel.py) at its real geometry -- 224 px, L = 128 -- in f32 mode against the CPU oracle run in the same
+    test (batch 8: the CPU leg takes seconds; the reference's batch 64 is eight such batches).  No ReLU / max-pool sits in this
+    model (GELU, LayerNorm), so unlike C2 / C3 every gradient is held to the f32 bound directly: logits 1e-4 of max|ref|,
+    arg-max exact, loss 1e-4, each parameter gradient 1e-3 relative L2 against the CPU f32 oracle (f32 accumulation order
+    differs; the f64 run reports what f32 itself is worth)."""
+    from ConNexT.models.ourmodel import OurClassfierConvnextV2
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    B, classes = 8, 7
+    oracle = load_procedural(om.OConNeXT(classes, BERT_BASE, {}), 55).train()
+    os.environ["HAMSPINE_BERT_RANDOM_INIT"] = "1"
+    try:
+        net = OurClassfierConvnextV2(num_labels=classes, pretrained=False, bert_path=_bert_dir(tmp_path))
+    finally:
+        os.environ.pop("HAMSPINE_BERT_RANDOM_INIT", None)
+    want = net.state_dict()
+    mapped = {_tv_key(k): v for k, v in oracle.state_dict().items() if _tv_key(k) is not None}
+    net.load_state_dict({k: v.reshape(want[k].shape) for k, v in mapped.items()}, strict=True)
+    net = net.to(DEV).train()
+    # torchvision's convnext_base carries stochastic depth (p up to 0.5, random per sample in train mode); the HF branch the
+    # oracle restates has drop_path_rate 0 -- switch the random row drops off so the two run the same arithmetic
+    n_sd = 0
+    for m in net.image_encoder.modules():
+        if getattr(m, "sd_prob", 0.0) > 0.0:
+            m.sd_prob, n_sd = 0.0, n_sd + 1
+    assert n_sd == 35, n_sd                 # 36 blocks, the first has p = 0
+    images, ids, mask, labels = synthetic_batch(B, 224, 128, 30522, classes, seed=47, min_len=16)
+
+    def cpu_run(dtype):
+        oracle.zero_grad(set_to_none=True)
+        lg = oracle({"input_ids": ids, "attention_mask": mask, "transformed_image": images.to(dtype)})
+        ls = torch.nn.functional.cross_entropy(lg, labels)
+        ls.backward()
+        return lg.detach(), ls.detach(), _grads(oracle)
+
+    ref, ref_loss, g32 = cpu_run(torch.float32)
+    oracle.double()
+    _, _, g64 = cpu_run(torch.float64)
+    oracle.float()
+    g32, g64 = ({_tv_key(k): g.reshape(want[_tv_key(k)].shape) for k, g in d.items()} for d in (g32, g64))
+
+    hamspine.set_compute_dtype("f32")
+    from hamspine import functional as F
+    logits = net({"input_ids": ids.to(DEV), "attention_mask": mask.to(DEV), "transformed_image": images.to(DEV)})
+    loss = F.cross_entropy(logits, labels.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    _logits_ok(logits, ref, "C4 f32 logits", LOGIT_TOL)
+    assert torch.equal(logits.argmax(1).cpu(), ref.argmax(1)), "argmax must be bit-exact"
+    assert abs(loss.item() - ref_loss.item()) <= 1e-4 * abs(ref_loss.item()), (loss.item(), ref_loss.item())
+    pgr = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    assert sorted(pgr) == sorted(g32), set(pgr) ^ set(g32)
+    worst, worst_cpu = ("", 0.0), ("", 0.0)
+    for k, g in pgr.items():
+        if k.endswith(("key.bias", "key_conv.bias")):
+            continue                       # analytically zero (softmax shift invariance): rounding noise on every side
+        e, e_cpu = _relerr(g, g64[k]), (g32[k] - g64[k]).norm().item() / max(g64[k].norm().item(), 1e-30)
+        if e > worst[1]:
+            worst = (k, e)
+        if e_cpu > worst_cpu[1]:
+            worst_cpu = (k, e_cpu)
+        assert e <= 10.0 * e_cpu + 1e-3, f"C4 f32 grad {k}: {e:.3e} from f64 (CPU f32: {e_cpu:.3e})"
+    print(f"C4 f32 gradients vs f64: worst product {worst[1]:.2e} ({worst[0]}), worst CPU f32 {worst_cpu[1]:.2e} ({worst_cpu[0]})")
