@@ -70,6 +70,7 @@ typedef struct hs_conv_geom {
     int32_t no_bounds;       /* 1: the input is pre-padded, skip the h/w range test             */
 } hs_conv_geom;
 
+struct hs_bn_params;
 typedef struct hs_gemm_params {
     int32_t dtype;           /* element type of A and B (HS_F32 | HS_BF16)                      */
     int32_t a_kind, b_kind;
@@ -134,6 +135,12 @@ typedef struct hs_gemm_params {
     const float* bnb_mean;
     const float* bnb_invstd;
     float* bnb_partials;
+    /* optional (with colstats, when hs_gemm_bn_finish_rows(p) > 0): the launch also FINISHES the statistics of the BatchNorm
+       that follows -- the last workgroup of each column tile merges the tile rows' partials and writes bn_finish->save_mean /
+       save_invstd / scale / shift and updates running_mean / running_var (train-mode arithmetic of hs_batchnorm_fwd: biased
+       variance for normalisation, unbiased for running_var).  colstats must then hold hs_gemm_bn_finish_rows(p) rows.  The
+       caller runs hs_batchnorm_fwd with stats_done = 1 (apply pass only): one launch per BatchNorm less on the stream. */
+    const struct hs_bn_params* bn_finish;
 } hs_gemm_params;
 
 hs_status hs_gemm(const hs_gemm_params* p, void* stream);
@@ -141,6 +148,9 @@ hs_status hs_gemm(const hs_gemm_params* p, void* stream);
 int64_t hs_gemm_splitk_ws_bytes(const hs_gemm_params* p);
 /* number of row tiles hs_gemm will use for p (rows of a colstats buffer); 0 when p cannot produce colstats. */
 int32_t hs_gemm_stat_rows(const hs_gemm_params* p);
+/* rows the colstats buffer needs when the launch for p (colstats set) can also finish the BatchNorm statistics
+   (hs_gemm_params.bn_finish): tile rows + merge rows; 0 when this launch cannot. */
+int32_t hs_gemm_bn_finish_rows(const hs_gemm_params* p);
 /* tile rows of the launch hs_gemm makes for p (p->split_k as it will be launched): rows of bnb_partials */
 int32_t hs_gemm_tile_rows(const hs_gemm_params* p);
 /* heuristic split-K factor for a (M,N,K) problem so that the grid fills 256 CUs. */
@@ -193,6 +203,8 @@ typedef struct hs_bn_params {
     int64_t ws_bytes;
     int32_t partial_rows;    /* > 0: ws already holds that many rows of (count, mean, M2) partials per channel
                                 (hs_gemm colstats): skip the statistics pass over x                */
+    int32_t stats_done;      /* 1: save_mean / save_invstd / scale / shift (and the running statistics) are already
+                                written (hs_gemm_params.bn_finish): apply pass only                 */
 } hs_bn_params;
 
 typedef struct hs_bn_bwd_params {

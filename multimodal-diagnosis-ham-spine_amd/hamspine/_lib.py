@@ -54,6 +54,7 @@ class GemmParams(C.Structure):
         ("seg_rows", i32), ("D_seg", vp * 2), ("colscale", vp), ("residual_before_act", i32), ("colstats", vp),
         ("rowsum_a", vp), ("rowsum_seg", vp * 2),
         ("bnb_x", vp), ("bnb_scale", vp), ("bnb_shift", vp), ("bnb_mean", vp), ("bnb_invstd", vp), ("bnb_partials", vp),
+        ("bn_finish", vp),
     ]
 
 
@@ -64,6 +65,7 @@ class BnParams(C.Structure):
         ("x", vp), ("residual", vp), ("y", vp), ("gamma", vp), ("beta", vp),
         ("running_mean", vp), ("running_var", vp), ("save_mean", vp), ("save_invstd", vp),
         ("scale", vp), ("shift", vp), ("ws", vp), ("ws_bytes", i64), ("partial_rows", i32),
+        ("stats_done", i32),
     ]
 
 
@@ -172,6 +174,8 @@ def _declare(l):
     l.hs_gemm_splitk_ws_bytes.argtypes = [P(GemmParams)]
     l.hs_gemm_splitk_ws_bytes.restype = i64
     l.hs_gemm_stat_rows.argtypes = [P(GemmParams)]
+    l.hs_gemm_bn_finish_rows.argtypes = [P(GemmParams)]
+    l.hs_gemm_bn_finish_rows.restype = i32
     l.hs_gemm_tile_rows.argtypes = [P(GemmParams)]
     l.hs_gemm_tile_rows.restype = i32
     l.hs_gemm_suggest_split.argtypes = [i32] * 4

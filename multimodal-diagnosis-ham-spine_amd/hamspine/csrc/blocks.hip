@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void gather3_kernel(const float* __restrict__ 
 
 int gemm_impl(const hs_gemm_params* p, hipStream_t stream);
 int gemm_stat_rows(const hs_gemm_params* p);
+int gemm_bn_finish_rows(const hs_gemm_params* p);
 int gemm_tile_rows(const hs_gemm_params* p);
 struct GemmGroup;
 GemmGroup* gemm_group_open(hipStream_t s, long long slot);   // slot: any key that is stable across steps (its device table is cached)
@@ -637,8 +638,17 @@ struct FoldedBn {          // eval-mode BatchNorm folded into the convolution: y
     int relu = 0;
     const void* identity = nullptr;
 };
+static bool bn_finish_enabled() {     // HAMSPINE_BN_FINISH=0: BatchNorm finishes its statistics in its own launch
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("HAMSPINE_BN_FINISH");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+// bn (optional, with stats): the BatchNorm that follows; when the launch can it finishes the statistics too (bn->stats_done)
 static int conv_fwd_run(Run& r, const ConvShape& s, const void* x, const void* w_c, void* y, float* stats = nullptr,
-                        int* stat_rows = nullptr, const FoldedBn* fold = nullptr) {
+                        int* stat_rows = nullptr, const FoldedBn* fold = nullptr, hs_bn_params* bn = nullptr) {
     hs_gemm_params p = gemm_defaults(r.dt);
     if (fold) {
         p.colscale = fold->scale;
@@ -667,6 +677,13 @@ static int conv_fwd_run(Run& r, const ConvShape& s, const void* x, const void* w
         if (rows > 0) {
             p.colstats = stats;
             *stat_rows = rows;
+            if (bn && bn->training && bn_finish_enabled()) {
+                const int frows = gemm_bn_finish_rows(&p);
+                if (frows > 0 && bn->ws == (void*)stats && bn->ws_bytes >= (long long)frows * s.Cout * 3 * 4) {
+                    p.bn_finish = bn;
+                    bn->stats_done = 1;
+                }
+            }
         }
     }
     CALL(r, gemm_impl(&p, r.s));
@@ -872,10 +889,11 @@ static int resblock_fwd_run(Run& r, const hs_resblock_desc& d, const void* x, vo
     if (d.has_ds) {
         const long long Mo = (long long)d.N * L.ds.s.P * L.ds.s.Q;
         int srows = 0;
-        HS_PROPAGATE(conv_fwd_run(r, L.ds.s, x, L.ds.w_c, L.ds.c, d.training ? (float*)L.bn_ws : nullptr, &srows));
         hs_bn_params bp = bn_params(r, d, d.ds, L.ds, Mo);
         bp.y = L.ds.a; bp.relu = 0;
-        bp.ws = L.bn_ws; bp.ws_bytes = L.bn_ws_bytes; bp.partial_rows = srows;
+        bp.ws = L.bn_ws; bp.ws_bytes = L.bn_ws_bytes;
+        HS_PROPAGATE(conv_fwd_run(r, L.ds.s, x, L.ds.w_c, L.ds.c, d.training ? (float*)L.bn_ws : nullptr, &srows, nullptr, &bp));
+        bp.partial_rows = srows;
         CALLK(r, 8, hs_batchnorm_fwd(&bp, r.s));
         identity = L.ds.a;
     }
@@ -884,13 +902,14 @@ static int resblock_fwd_run(Run& r, const hs_resblock_desc& d, const void* x, vo
         StageBuf& b = L.main[i];
         const long long Mo = (long long)d.N * b.s.P * b.s.Q;
         int srows = 0;
-        HS_PROPAGATE(conv_fwd_run(r, b.s, in, b.w_c, b.c, d.training ? (float*)L.bn_ws : nullptr, &srows));
         hs_bn_params bp = bn_params(r, d, d.main[i], b, Mo);
         const bool last = i + 1 == d.n_main;
         bp.y = last ? y : b.a;
         bp.relu = 1;
         bp.residual = last ? identity : nullptr;
-        bp.ws = L.bn_ws; bp.ws_bytes = L.bn_ws_bytes; bp.partial_rows = srows;
+        bp.ws = L.bn_ws; bp.ws_bytes = L.bn_ws_bytes;
+        HS_PROPAGATE(conv_fwd_run(r, b.s, in, b.w_c, b.c, d.training ? (float*)L.bn_ws : nullptr, &srows, nullptr, &bp));
+        bp.partial_rows = srows;
         CALLK(r, 8, hs_batchnorm_fwd(&bp, r.s));
         in = b.a;
     }
@@ -1066,7 +1085,6 @@ static int stem_fwd_run(Run& r, const hs_stem_desc& d, const float* image, void*
     }
     int srows = 0;
     if (d.training && fused_bn_stats_enabled() && (srows = gemm_stat_rows(&p)) > 0) p.colstats = (float*)L.bn_ws;
-    CALL(r, gemm_impl(&p, r.s));
     hs_bn_params bp;
     memset(&bp, 0, sizeof(bp));
     bp.dtype = r.dt; bp.C = cb.Cout; bp.M = Mo;
@@ -1078,6 +1096,14 @@ static int stem_fwd_run(Run& r, const hs_stem_desc& d, const float* image, void*
     bp.running_mean = cb.running_mean; bp.running_var = cb.running_var;
     bp.save_mean = L.mean; bp.save_invstd = L.invstd; bp.scale = L.scale; bp.shift = L.shift;
     bp.ws = L.bn_ws; bp.ws_bytes = L.bn_ws_bytes;
+    if (p.colstats && bn_finish_enabled()) {
+        const int frows = gemm_bn_finish_rows(&p);
+        if (frows > 0 && L.bn_ws_bytes >= (long long)frows * cb.Cout * 3 * 4) {
+            p.bn_finish = &bp;
+            bp.stats_done = 1;
+        }
+    }
+    CALL(r, gemm_impl(&p, r.s));
     CALLK(r, 8, hs_batchnorm_fwd(&bp, r.s));
     CALL(r, hs_maxpool_fwd(r.dt, L.a, y, L.idx, d.N, L.P, L.Q, cb.Cout, 3, 2, 1, r.s));
     return HS_OK;

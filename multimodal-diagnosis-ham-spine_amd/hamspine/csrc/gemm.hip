@@ -130,6 +130,11 @@ int gemm_stat_rows(const hs_gemm_params* p) {
     return ceil_div(p->M, cfg == CFG_64x64 ? 64 : (cfg == CFG_256x128 || cfg == CFG_256x128x32) ? 256 : 128);
 }
 
+// tiles / layouts with a BatchNorm-finishing kernel variant (gemm_bf16_bnf_kernel): forward convolutions and 1x1 convolutions
+static bool bn_finish_variant(int cfg, int combo) {
+    return (combo == 0 && (cfg == CFG_64x64 || cfg == CFG_128x64)) || (combo == 3 && (cfg == CFG_64x64 || cfg == CFG_128x64 || cfg == CFG_STEM));
+}
+
 // everything gemm_impl decides before the launch
 struct Prepared {
     GemmArgs a;
@@ -356,6 +361,19 @@ static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q
         }
     }
     if (a.colstats) HS_REQUIRE(bf16 && split == 1 && batch == 1, "hs_gemm: colstats needs bf16 operands, no split-K, no batch");
+    if (p->bn_finish) {        // the launch also finishes the BatchNorm statistics (BNF kernels; hs_gemm_bn_finish_rows said it can)
+        const hs_bn_params* f = p->bn_finish;
+        HS_REQUIRE(a.colstats && bn_finish_variant(cfg, combo), "hs_gemm: bn_finish needs colstats and a tile / layout hs_gemm_bn_finish_rows accepts");
+        HS_REQUIRE(f->training && f->C == p->N && f->M == p->M && f->save_mean && f->save_invstd && f->scale && f->shift,
+                   "hs_gemm: bn_finish needs a training-mode hs_bn_params of the result's shape with save_mean / save_invstd / scale / shift");
+        HS_REQUIRE((long long)a.tiles_n * (1 + stat_groups(a.tiles_m)) <= kTicketPool, "hs_gemm: bn_finish: too many column tiles");
+        a.bnf_gamma = f->gamma; a.bnf_beta = f->beta;
+        a.bnf_rmean = f->running_var ? f->running_mean : nullptr; a.bnf_rvar = f->running_var;
+        a.bnf_mean = f->save_mean; a.bnf_invstd = f->save_invstd; a.bnf_scale = f->scale; a.bnf_shift = f->shift;
+        a.bnf_eps = f->eps; a.bnf_momentum = f->momentum;
+        a.bnf_tickets = ticket_pool(stream);
+        HS_REQUIRE(a.bnf_tickets != nullptr, "hs_gemm: cannot allocate the arrival counters");
+    }
     {   // measurement aid (HAMSPINE_EPI_HIST=1): which epilogue feature sets the launches use, printed at exit
         static const bool hist = [] { const char* e = getenv("HAMSPINE_EPI_HIST"); return e && e[0] == '1'; }();
         if (hist) {
@@ -397,7 +415,7 @@ static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q
         // (or hs_gemm_debug ablation bit 64).
         static const bool on = [] { const char* e = getenv("HAMSPINE_PERSISTENT"); return e && e[0] == '1'; }();
         static const int cus = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
-        if ((on || (g_dbg_ablate & 64)) && bf16 && split == 1 && batch == 1 && !a.stamps && !p->rowsum_a && !p->bnb_partials && (cfg == CFG_64x64 || cfg == CFG_128x64) &&
+        if ((on || (g_dbg_ablate & 64)) && bf16 && split == 1 && batch == 1 && !a.stamps && !p->rowsum_a && !p->bnb_partials && !p->bn_finish && (cfg == CFG_64x64 || cfg == CFG_128x64) &&
             (combo == 0 || combo == 1 || combo == 3 || combo == 4)) {
             const int lds = a.lds_stages * (BM + BN) * 64 * 2;
             const int per_cu = std::max(1, std::min(cfg == CFG_64x64 ? 3 : 2, (160 * 1024) / lds));   // 168 / 256 VGPRs, LDS
@@ -434,6 +452,18 @@ int gemm_tile_rows(const hs_gemm_params* p) {
     Prepared q;
     if (gemm_prepare(&c, nullptr, q) != HS_OK) return 0;
     return q.a.tiles_m;
+}
+
+// rows of the colstats buffer when the launch for p can also finish the BatchNorm statistics (tile rows + group rows), else 0
+int gemm_bn_finish_rows(const hs_gemm_params* p) {
+    if (!p || !p->colstats) return 0;
+    hs_gemm_params c = *p;
+    c.bn_finish = nullptr;
+    Prepared q;
+    if (gemm_prepare(&c, nullptr, q) != HS_OK) return 0;
+    if (!q.bf16 || q.split != 1 || q.batch != 1 || q.a.persist > 0 || !bn_finish_variant(q.cfg, q.combo)) return 0;
+    if ((long long)q.a.tiles_n * (1 + stat_groups(q.a.tiles_m)) > kTicketPool) return 0;
+    return q.a.tiles_m + stat_groups(q.a.tiles_m);
 }
 
 int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
@@ -681,6 +711,7 @@ int hs_device_ok(void) {
 }
 hs_status hs_gemm(const hs_gemm_params* p, void* stream) { return hs::gemm_impl(p, (hipStream_t)stream); }
 int32_t hs_gemm_stat_rows(const hs_gemm_params* p) { return hs::gemm_stat_rows(p); }
+int32_t hs_gemm_bn_finish_rows(const hs_gemm_params* p) { return hs::gemm_bn_finish_rows(p); }
 int32_t hs_gemm_tile_rows(const hs_gemm_params* p) { return hs::gemm_tile_rows(p); }
 int64_t hs_gemm_splitk_ws_bytes(const hs_gemm_params* p) {
     if (!p || p->split_k <= 1) return 0;

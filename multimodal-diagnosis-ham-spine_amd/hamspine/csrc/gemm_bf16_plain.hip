@@ -22,6 +22,12 @@ int launch_bf16_plain(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStrea
         set_error("launch_bf16_plain: no BatchNorm-sum variant for cfg/combo %d/%d", cfg, combo);
         return HS_ERR_ARG;
     }
+    if (a.bnf_tickets) {      // 1x1 convolution (forward) + the following BatchNorm's statistics, finished in the launch
+        if (combo == 0 && cfg == CFG_64x64) return launch_with_lds(gemm_bf16_bnf_kernel<64, 64, 64, HS_A_KC, HS_B_KC>, a.lds_stages * 128 * 64 * 2, 3 * 128 * 64 * 2, a, grid, s);
+        if (combo == 0 && cfg == CFG_128x64) return launch_with_lds(gemm_bf16_bnf_kernel<128, 64, 64, HS_A_KC, HS_B_KC>, a.lds_stages * 192 * 64 * 2, 3 * 192 * 64 * 2, a, grid, s);
+        set_error("launch_bf16_plain: no BatchNorm-finishing variant for cfg/combo %d/%d", cfg, combo);
+        return HS_ERR_ARG;
+    }
     if (a.persist > 0) {      // more tiles than resident workgroups: the persistent variant (no split-K, no row sums)
         if (combo == 0 && cfg == CFG_64x64) return launch_with_lds(gemm_bf16_persistent_kernel<64, 64, HS_A_KC, HS_B_KC>, a.lds_stages * 128 * 64 * 2, 3 * 128 * 64 * 2, a, grid, s);
         if (combo == 0 && cfg == CFG_128x64) return launch_with_lds(gemm_bf16_persistent_kernel<128, 64, HS_A_KC, HS_B_KC>, a.lds_stages * 192 * 64 * 2, 3 * 192 * 64 * 2, a, grid, s);

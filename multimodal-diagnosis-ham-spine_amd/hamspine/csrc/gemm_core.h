@@ -72,6 +72,13 @@ struct GemmArgs {
     const char* bnb_x;
     const float *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd;
     float* bnb_partials;
+    // optional (BNF kernels, with colstats): the launch also FINISHES the following BatchNorm's statistics -- the last workgroup
+    // of a column tile merges the row tiles' partials and writes mean / invstd / scale / shift (+ running statistics); see
+    // hs_gemm_params.bn_finish.  bnf_tickets: tiles_n * (1 + stat_groups(tiles_m)) zeroed arrival counters.
+    const float *bnf_gamma, *bnf_beta;
+    float *bnf_rmean, *bnf_rvar, *bnf_mean, *bnf_invstd, *bnf_scale, *bnf_shift;
+    float bnf_eps, bnf_momentum;
+    unsigned* bnf_tickets;
     float* rowsum[3];          // optional (row-contiguous A): rowsum[seg][m] = sum_k A[k][m], the bias gradient of a wgrad GEMM
     int vec16;                    // bf16 result rows allow 16-byte (8-column) stores: N, ldd, batch strides % 8 == 0, bases 16-byte aligned
     int epi_generic;              // measurement only (hs_gemm_debug bit 32): always take the generic epilogue body
@@ -491,6 +498,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 // in-launch split-K: slices hand their slabs off in groups of this many (gemm_bf16_kernel); the workspace holds one slab per
 // slice plus, for more than one group, one per group
 constexpr int kSplitGroup = 8;
+constexpr int kStatGroup = 32;     // row tiles whose BatchNorm partials one hand-off merges (BNF kernels)
+__host__ __device__ inline int stat_groups(int tiles_m) { return tiles_m <= kStatGroup ? 0 : (tiles_m + kStatGroup - 1) / kStatGroup; }
 inline long long splitk_slabs(int split) { return split <= kSplitGroup ? split : split + (split + kSplitGroup - 1) / kSplitGroup; }
 
 constexpr bool a_is_rc(int k) { return k == HS_A_RC; }
@@ -607,8 +616,9 @@ __device__ __forceinline__ void wait_vm_tiles(int tiles) {       // wait until a
 // SK: the launch may be a split-K one (false: the slab / hand-off code is left out -- its registers count against every launch).
 // PS: persistent-capable (the tile loop and the next-tile prefetch are compiled in; costs registers, so it is a variant).
 // BNS: the epilogue can also take the BatchNorm-backward sums of the result (a.bnb_partials; data gradients of ResNet blocks).
+// BNF: a colstats launch can also finish the BatchNorm statistics (a.bnf_tickets; forward convolutions of ResNet blocks).
 template <int BM, int BN, int BK, int AK, int BKIND, bool VEC, int WGM = 2, bool RS = false, int NS = 3, bool SK = true, bool PS = false,
-          bool BNS = false>
+          bool BNS = false, bool BNF = false>
 __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, const int bz) {
     typedef bf16_t T;
     constexpr int ESZ = 2;
@@ -966,9 +976,28 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
             }
             const float cnt = (float)min(BM, a.M - m0);
             float* o = a.colstats + ((long long)tm * a.N + n0 + tid) * 3;
-            o[0] = cnt;
-            o[1] = t1 / cnt;
-            o[2] = fmaxf(t2 - t1 * t1 / cnt, 0.f);
+            const float mean = t1 / cnt, m2 = fmaxf(t2 - t1 * t1 / cnt, 0.f);
+            if constexpr (BNF) {               // read by another workgroup of this launch: write-through (see the hand-off below)
+                __hip_atomic_store(o, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(o + 1, mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(o + 2, m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                o[0] = cnt;
+                o[1] = mean;
+                o[2] = m2;
+            }
+        }
+    }
+    // (BNF) this tile's arrival at the statistics hand-off (see the end of the body) is drawn here, so that the counter's
+    // round trip runs under the epilogue and only the three partial stores above are waited for, not the result's stores
+    int bnf_drawn = 0;
+    if constexpr (BNF && !PS) {
+        if (a.bnf_tickets) {
+            const int ng = stat_groups(a.tiles_m);
+            unsigned* ticket = ng ? a.bnf_tickets + a.tiles_n + tn * ng + tm / kStatGroup : a.bnf_tickets + tn;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the partial stores have left
+            __syncthreads();
+            if (tid == 0) bnf_drawn = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 
@@ -1250,6 +1279,125 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
     }
     if (!done) run_epilogue<T, -1, false, FM, FN, WM, WN>(a, epi, acc, em0, en0, wm, wn, l15, g, d_boff, ze);
     HS_STAMP(4);
+    if constexpr (BNF && !PS) {
+        if (a.bnf_tickets) {
+            // The statistics of the following BatchNorm are finished inside the launch (the separate bn_stats_final_kernel sat on
+            // the ResNet stream's critical path 53 times a step: ~7 us each + a dispatch gap, for microseconds of arithmetic).
+            // Same hand-off as the split-K reduction above: write-through partials -> vmcnt(0) -> barrier -> one relaxed
+            // agent-scope ticket; the workgroup that arrives last acquires and merges.  Two levels so that the tail stays
+            // short: the row tiles of a column tile hand off in groups of kStatGroup (the last of a group merges it into one
+            // (count, mean, M2) row behind the tile rows), then the last group merges the group rows and writes the
+            // statistics.  Merging is the grouped formula (n = sum n_i, mean = sum n_i mean_i / n,
+            // M2 = sum M2_i + n_i (mean_i - mean)^2, evaluated about a shift) in a fixed order: deterministic whichever tile
+            // arrives last.
+            constexpr int NT = WGM * 128, TPC = NT / BN, UB = 8;
+            static_assert(NT % BN == 0 && TPC >= 1, "threads per column");
+            float* sh = (float*)smem;                                  // [TPC][BN][3]; the ring is free
+            int* flag = (int*)(sh + NT * 3);
+            const int tiles_m = a.tiles_m, ngroups = stat_groups(tiles_m);
+            const int col = tid % BN, sub = tid / BN, n = en0 + col;
+            const bool cok = n < argN;
+            const int grp = tm / kStatGroup;
+            int first = ngroups ? grp * kStatGroup : 0, count = ngroups ? min(kStatGroup, tiles_m - first) : tiles_m;
+            unsigned* ticket = ngroups ? a.bnf_tickets + a.tiles_n + tn * ngroups + grp : a.bnf_tickets + tn;
+            const unsigned st_bytes = (unsigned)min((unsigned long long)(tiles_m + ngroups) * argN * 12ull, 0x7fffff00ull);
+            const __amdgpu_buffer_rsrc_t rsS = make_rsrc(a.colstats, st_bytes);
+            float cnt = 0.f, mean = 0.f, m2 = 0.f;
+            bool early = true;                                         // the first hand-off's ticket was drawn before the epilogue
+#pragma unroll 1
+            for (int level = ngroups ? 0 : 1; level < 2; ++level) {
+                if (!early) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the group row's stores have left
+                    __syncthreads();
+                    if (tid == 0) bnf_drawn = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                early = false;
+                if (tid == 0) *flag = bnf_drawn;
+                __syncthreads();
+                const int drawn = *flag;
+                __syncthreads();
+                if (drawn != count - 1) return;                        // (workgroup-uniform)
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the next launch
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                // one pass, every load of a batch in flight together (dependent passes cost a memory round trip each on the
+                // launch's tail).  Each thread sums n_i, n_i d_i and M2_i + n_i d_i^2 of its rows with d_i = mean_i - k, k = the
+                // mean of the thread's FIRST row (any row's mean is within a tile's standard error of the answer, so the final
+                // S2 - S1^2 / S0 cancels nothing; the first row rather than this workgroup's own tile so that the rounding does
+                // not depend on which tile arrived last); the TPC threads of a column then merge their triples the same way.
+                float k = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+                for (int r0 = sub; r0 < count; r0 += TPC * UB) {
+                    float v[UB][3];
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const int r = r0 + u * TPC;
+                        const unsigned off = (cok && r < count) ? (unsigned)(((long long)(first + r) * argN + n) * 12) : kOOB;
+#pragma unroll
+                        for (int e = 0; e < 3; ++e)
+                            v[u][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsS, off + 4 * e, 0, 16 /* sc1: written by other XCDs */));
+                    }
+                    if (r0 == sub) k = v[0][1];
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {                      // rows past the range read as zeros: no contribution
+                        const float c = v[u][0], d = v[u][1] - k;
+                        s0 += c;
+                        s1 = fmaf(c, d, s1);
+                        s2 += fmaf(c * d, d, v[u][2]);
+                    }
+                }
+                {
+                    const float dm = s0 > 0.f ? s1 / s0 : 0.f;
+                    sh[(sub * BN + col) * 3] = s0;
+                    sh[(sub * BN + col) * 3 + 1] = k + dm;
+                    sh[(sub * BN + col) * 3 + 2] = fmaxf(s2 - s1 * dm, 0.f);
+                }
+                __syncthreads();
+                k = sh[col * 3 + 1];                                   // thread 0 of the column always has a row
+                s0 = 0.f; s1 = 0.f; s2 = 0.f;
+#pragma unroll
+                for (int u = 0; u < TPC; ++u) {
+                    const float c = sh[(u * BN + col) * 3], d = sh[(u * BN + col) * 3 + 1] - k;
+                    s0 += c;
+                    s1 = fmaf(c, d, s1);
+                    s2 += fmaf(c * d, d, sh[(u * BN + col) * 3 + 2]);
+                }
+                __syncthreads();
+                cnt = s0;
+                const float dm = s0 > 0.f ? s1 / s0 : 0.f;
+                mean = k + dm;
+                m2 = fmaxf(s2 - s1 * dm, 0.f);
+                if (level == 0) {
+                    if (sub == 0 && cok) {
+                        float* o = a.colstats + ((long long)(tiles_m + grp) * argN + n) * 3;
+                        __hip_atomic_store(o, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(o + 1, mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(o + 2, m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    first = tiles_m;
+                    count = ngroups;
+                    ticket = a.bnf_tickets + tn;
+                }
+            }
+            if (sub == 0 && cok) {                                     // the launch's last workgroup of this column tile
+                const float rows = (float)argM;
+                const float var = m2 / rows;                           // biased, used for normalisation
+                const float invstd = rsqrtf(var + a.bnf_eps);
+                a.bnf_mean[n] = mean;
+                a.bnf_invstd[n] = invstd;
+                const float gm = a.bnf_gamma ? a.bnf_gamma[n] : 1.f, bt = a.bnf_beta ? a.bnf_beta[n] : 0.f;
+                a.bnf_scale[n] = gm * invstd;
+                a.bnf_shift[n] = bt - mean * gm * invstd;
+                if (a.bnf_rmean) {
+                    const float unbiased = argM > 1 ? m2 / (rows - 1.f) : var;
+                    a.bnf_rmean[n] = (1.f - a.bnf_momentum) * a.bnf_rmean[n] + a.bnf_momentum * mean;
+                    a.bnf_rvar[n] = (1.f - a.bnf_momentum) * a.bnf_rvar[n] + a.bnf_momentum * unbiased;
+                }
+            }
+        }
+    }
     if (!more) break;
     vb = nvb;
     first_tile = false;
@@ -1264,6 +1412,11 @@ __global__ __launch_bounds__(WGM * 128) void gemm_bf16_kernel(const GemmArgs a) 
 template <int BM, int BN, int AK, int BKIND>
 __global__ __launch_bounds__(256) void gemm_bf16_bns_kernel(const GemmArgs a) {
     gemm_bf16_body<BM, BN, 64, AK, BKIND, true, 2, false, 3, true, false, true>(a, blockIdx.x, blockIdx.z);
+}
+// forward convolutions that also finish the following BatchNorm's statistics (a.colstats + a.bnf_tickets)
+template <int BM, int BN, int BK, int AK, int BKIND>
+__global__ __launch_bounds__(256) void gemm_bf16_bnf_kernel(const GemmArgs a) {
+    gemm_bf16_body<BM, BN, BK, AK, BKIND, true, 2, false, 3, false, false, false, true>(a, blockIdx.x, blockIdx.z);
 }
 // persistent-capable variant (64x64 and 128x64 tiles): launched with a.persist = grid size when a GEMM has more tiles than
 // the chip holds at once

@@ -401,7 +401,9 @@ static int bn_fwd_t(const hs_bn_params* p, hipStream_t s) {
     HS_REQUIRE(p->C % E == 0, "bn: C %% %d != 0", E);
     const long long M = p->M;
     const int C = p->C;
-    if (p->training) {
+    if (p->training && p->stats_done) {
+        // the producing GEMM finished the statistics as well (hs_gemm_params.bn_finish): scale / shift are in place
+    } else if (p->training) {
         ColGeom g = col_geom(M, C, E);
         int rows = g.gy;
         if (p->partial_rows > 0) {     // the producing GEMM already left (count, mean, M2) per row tile in ws
@@ -474,7 +476,9 @@ long long bn_ws_bytes(long long M, int C, int dtype) {
     ColGeom g = col_geom(M, C, dtype == HS_BF16 ? 8 : 4);
     // partials (3 floats/channel/row block; up to one row per 64-row GEMM tile when the convolution supplies them) + bwd
     // coefficients
-    const long long rows = std::max<long long>(g.gy, (M + 63) / 64);
+    // (+ the merge rows of a GEMM that also finishes the statistics: one per 32 tile rows, hs_gemm_bn_finish_rows)
+    const long long tiles = (M + 63) / 64;
+    const long long rows = std::max<long long>(g.gy, tiles + (tiles + 31) / 32);
     return rows * C * 3 * 4 + 4ll * C * 4;
 }
 

@@ -48,8 +48,11 @@ def conv_geom(N, H, W, Cin, Kout, R, S, stride, pad, row_pitch=None, img_pitch=N
 def gemm(A, B, D, M, N, K, a_kind=L.A_KC, b_kind=L.B_KC, lda=0, ldb=0, ldd=None, geom=None,
          batch=1, batch_inner=1, a_bs=(0, 0), b_bs=(0, 0), d_bs=(0, 0), split_k=1,
          alpha=1.0, bias=None, act=L.ACT_NONE, preact=None, residual=None, ldr=None,
-         dropout_p=0.0, dropout_seed=0, mul_mode=L.MUL_NONE, mul_src=None, ldm=None, accumulate=False, rowsum_a=None, bnb=None):
+         dropout_p=0.0, dropout_seed=0, mul_mode=L.MUL_NONE, mul_src=None, ldm=None, accumulate=False, rowsum_a=None, bnb=None,
+         bn_finish=None):
     """D[m][n] = epi(alpha * sum_k A(m,k) B(n,k)); see include/hamspine.h for the operand kinds.
+    bn_finish = dict(gamma, beta, running_mean, running_var, eps, momentum): the launch also produces the train-mode
+    BatchNorm statistics of the result (hs_gemm_params.colstats + .bn_finish); returns (D, mean, invstd, scale, shift).
     bnb = (c, scale, shift, mean, invstd): also return the BatchNorm-backward partial sums of the result
     (hs_gemm_params.bnb_*) as a float tensor [tile rows][N][2]."""
     need_gpu(A, B, D, bias, preact, residual, mul_src, rowsum_a)
@@ -102,6 +105,26 @@ def gemm(A, B, D, M, N, K, a_kind=L.A_KC, b_kind=L.B_KC, lda=0, ldb=0, ldd=None,
             raise L.HamspineError("gemm: bnb is not available for this configuration")
         partials = torch.empty((rows, N, 2), dtype=torch.float32, device=A.device)
         p.bnb_partials = ptr(partials)
+    if bn_finish is not None:
+        f = bn_finish
+        p.colstats = 16                  # any non-null value: the row query only looks at the configuration
+        rows = int(L.lib().hs_gemm_bn_finish_rows(C.byref(p)))
+        if rows <= 0:
+            raise L.HamspineError("gemm: bn_finish is not available for this configuration")
+        stats_ws = torch.empty((rows, N, 3), dtype=torch.float32, device=A.device)
+        out = [torch.empty(N, dtype=torch.float32, device=A.device) for _ in range(4)]
+        need_gpu(f.get("gamma"), f.get("beta"), f.get("running_mean"), f.get("running_var"))
+        bp = L.BnParams()
+        bp.dtype, bp.C, bp.M, bp.training = p.dtype, N, M, 1
+        bp.eps, bp.momentum = f.get("eps", 1e-5), f.get("momentum", 0.1)
+        bp.gamma, bp.beta = ptr(f.get("gamma")), ptr(f.get("beta"))
+        bp.running_mean, bp.running_var = ptr(f.get("running_mean")), ptr(f.get("running_var"))
+        bp.save_mean, bp.save_invstd, bp.scale, bp.shift = (ptr(t) for t in out)
+        bp.ws, bp.ws_bytes = ptr(stats_ws), stats_ws.numel() * 4
+        p.colstats = ptr(stats_ws)
+        p.bn_finish = C.addressof(bp)
+        L.check(L.lib().hs_gemm(C.byref(p), stream_ptr()), "hs_gemm")
+        return (D, *out)
     L.check(L.lib().hs_gemm(C.byref(p), stream_ptr()), "hs_gemm")
     return (D, partials) if bnb is not None else D
 

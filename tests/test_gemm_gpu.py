@@ -355,3 +355,59 @@ def test_data_gradient_gemm_takes_the_batchnorm_backward_sums(M, N, K, split):
     tol2 = 1e-4 * (dz * xhat).abs().sum(0) + 1e-6
     assert ((s[:, 0] - want1).abs() <= tol1).all()
     assert ((s[:, 1] - want2).abs() <= tol2).all()
+
+
+@pytest.mark.parametrize("case", [
+    # (M, N, K) of 1x1 convolutions (K-contiguous operands): one merge level, two levels (ragged last group), ragged tiles
+    ("pw", 1568, 2048, 512), ("pw", 100352, 64, 64), ("pw", 25088, 512, 128), ("pw", 1000, 72, 320), ("pw", 6272 + 40, 256, 1024),
+    # (N, Cin, H, W, Cout, R, stride, pad) of implicit-GEMM convolutions (the 7x7 stem's launch: tests/test_tower_gpu.py)
+    ("conv", 32, 64, 56, 56, 64, 3, 1, 1), ("conv", 4, 128, 28, 28, 128, 3, 2, 1), ("conv", 2, 64, 14, 14, 512, 3, 1, 1)])
+def test_forward_gemm_finishes_the_batchnorm_statistics(case):
+    """hs_gemm_params.bn_finish: the forward (1x1 / implicit-GEMM) convolution also finishes the train-mode statistics of the
+    BatchNorm that follows -- mean, 1/sqrt(var + eps), scale = gamma * invstd, shift = beta - mean * scale and the running
+    statistics (biased variance for normalisation, unbiased for running_var, reference torch.nn.BatchNorm2d inside
+    torchvision's Bottleneck) -- in the same launch.  Checked against float64 statistics of the f32 accumulators' product
+    (the kernel takes them before the bf16 rounding of the stored result) and run twice: the arrival counters re-arm."""
+    g = torch.Generator().manual_seed(len(case) * 7 + case[1])
+    BF = torch.bfloat16
+    if case[0] == "pw":
+        _, M, N, K = case
+        A = (torch.randn(M, K, generator=g) * 0.5).to(BF).to(DEV)
+        W = (torch.randn(N, K, generator=g) * 0.1).to(BF).to(DEV)
+        ref = A.double() @ W.double().t()
+        kw = dict(a_kind=L.A_KC, b_kind=L.B_KC, lda=K, ldb=K)
+        args = (A, W)
+    else:
+        _, Nb, Cin, H, Wd, N, R, stride, pad = case
+        x = (torch.randn(Nb, Cin, H, Wd, generator=g) * 0.5).to(BF)
+        w = (torch.randn(N, Cin, R, R, generator=g) * 0.1).to(BF)
+        ref4 = torch.nn.functional.conv2d(x.double(), w.double(), stride=stride, padding=pad)
+        P, Q = ref4.shape[2:]
+        M, K = Nb * P * Q, R * R * Cin
+        ref = ref4.permute(0, 2, 3, 1).reshape(M, N).to(DEV)
+        geom = raw.conv_geom(Nb, H, Wd, Cin, N, R, R, stride, pad)
+        args = (x.to(DEV).contiguous(memory_format=torch.channels_last), w.to(DEV).contiguous(memory_format=torch.channels_last))
+        kw = dict(a_kind=L.A_CONV, b_kind=L.B_KC, ldb=K, geom=geom)
+    gamma = (torch.rand(N, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(N, generator=g) * 0.3).to(DEV)
+    rm0, rv0 = (torch.randn(N, generator=g) * 0.1).to(DEV), (torch.rand(N, generator=g) + 0.5).to(DEV)
+    eps, mom = 1e-5, 0.1
+    mean_ref = ref.mean(0)
+    var_ref = ref.var(0, unbiased=False)
+    for rep in range(2):
+        rm, rv = rm0.clone(), rv0.clone()
+        D = torch.full((M, N), float("nan"), dtype=BF, device=DEV)
+        D, mean, invstd, scale, shift = raw.gemm(*args, D, M, N, K, ldd=N, **kw,
+                                                 bn_finish=dict(gamma=gamma, beta=beta, running_mean=rm, running_var=rv, eps=eps, momentum=mom))
+        assert (D.double() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item() + 1e-6
+        sd = var_ref.sqrt()
+        assert ((mean.double() - mean_ref).abs() <= 1e-5 * (mean_ref.abs() + sd)).all(), rep
+        invstd_ref = 1.0 / (var_ref + eps).sqrt()
+        assert ((invstd.double() - invstd_ref).abs() <= 1e-4 * invstd_ref).all(), rep
+        assert ((scale.double() - gamma.double() * invstd_ref).abs() <= 1e-4 * (gamma.double() * invstd_ref).abs()).all()
+        shift_ref = beta.double() - mean_ref * gamma.double() * invstd_ref
+        assert ((shift.double() - shift_ref).abs() <= 1e-4 * (shift_ref.abs() + beta.double().abs() + 1.0)).all()
+        rm_ref = (1 - mom) * rm0.double() + mom * mean_ref
+        rv_ref = (1 - mom) * rv0.double() + mom * var_ref * M / (M - 1)
+        assert ((rm.double() - rm_ref).abs() <= 1e-5 * (rm_ref.abs() + sd)).all()
+        assert ((rv.double() - rv_ref).abs() <= 1e-4 * rv_ref.abs()).all()
