@@ -17,7 +17,7 @@ lib.hs_gemm_debug.argtypes = [C.c_int32, C.c_int32]
 lib.hs_prof_enable.argtypes = [C.c_int32]
 lib.hs_prof_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
 DEV, BF = "cuda", torch.bfloat16
-CFGS = {0: "128x128", 1: "128x64", 2: "64x64", 4: "256x128", 5: "128x128k32"}
+CFGS = {0: "128x128", 1: "128x64", 2: "64x64", 4: "256x128", 5: "128x128k32", 6: "256x128k32"}
 FLUSH = None
 
 
