@@ -250,6 +250,36 @@ def test_ctypes_mirrors_match_the_compiled_abi_structs():
     assert lib.hs_abi_sizeof(99) == -1
 
 
+def test_batchnorm_workspace_holds_the_in_launch_statistics_rows():
+    """Host logic only (no launch): for every 1x1-convolution shape of ResNet50 at batch 32 -- and at batch 1024 -- the
+    colstats buffer a BatchNorm-finishing GEMM needs (hs_gemm_bn_finish_rows: tile rows + one merge row per 32) fits the
+    workspace hs_batchnorm_ws_bytes sizes, and it is the tile-row count plus ceil(rows / 32) (0 merge rows up to 32 tiles)."""
+    import ctypes as C
+    import hamspine._lib as L
+    lib = L.lib()
+    for batch in (32, 1024):
+        for hw, cout, cin in ((56 * 56, 64, 64), (56 * 56, 256, 64), (28 * 28, 512, 128), (14 * 14, 1024, 256), (7 * 7, 2048, 512),
+                              (7 * 7, 512, 2048)):
+            M = batch * hw
+            p = L.GemmParams()
+            p.dtype = p.out_dtype = L.HS_BF16
+            p.a_kind, p.b_kind = L.A_KC, L.B_KC
+            p.M, p.N, p.K = M, cout, cin
+            p.A = p.B = p.D = p.colstats = 4096               # only the configuration is looked at
+            p.a_elems, p.b_elems = M * cin, cout * cin
+            p.lda = p.ldb = cin
+            p.ldd = cout
+            p.alpha = 1.0
+            rows, frows = lib.hs_gemm_stat_rows(C.byref(p)), lib.hs_gemm_bn_finish_rows(C.byref(p))
+            want = rows + (0 if rows <= 32 else -(-rows // 32))
+            # 0 = this launch's tile has no finishing variant (the 128x128 tiles of wide layers at large batch): BatchNorm
+            # then finishes its statistics in its own launch, as before
+            assert rows > 0 and frows in ((want,) if batch == 32 else (want, 0)), (M, cout, cin, rows, frows)
+            assert lib.hs_batchnorm_ws_bytes(M, cout, L.HS_BF16) >= max(frows, rows) * cout * 12, (M, cout, cin)
+    p.colstats = None
+    assert lib.hs_gemm_bn_finish_rows(C.byref(p)) == 0        # no statistics requested: nothing to finish
+
+
 def test_product_refuses_cpu_tensors():
     import hamspine
     from hamspine import functional as F
