@@ -296,12 +296,22 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, unsigned rt_flags, 
 // LDS layouts
 // ------------------------------------------------------------------------------------------------
 // bf16, K-contiguous tile [rows][BK]: 16-byte chunk `kc` of row `r`.
+// XOR swizzle of the chunk index, a function of the row's 256-byte bank row j.  ds_read_b128 serves a wave in four groups of 16
+// lanes that are NOT contiguous ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...: micro-architecture guide, LDS table), and a
+// fragment read has lane = 16 g + row, chunk = g.  BK = 64 (8 chunks per row): swz = j puts the 16 lanes of every group on 16
+// different 16-byte bank quads.  BK = 32 (4 chunks per row): swz = j was a 2-way conflict in every group (rows 0-3 with chunk 0
+// and rows 4-7 with chunk 1 ^ 1 met on the same quads; SQ_LDS_BANK_CONFLICT = 48 % of SQ_LDS_IDX_ACTIVE on the 128x128x32
+// kernel) -- swz = (-j) mod 4 = {0, 3, 2, 1} separates them: {s0, s3, 1^s1, 1^s2} = {0, 1, 2, 3} and likewise for the other groups.
+template <int CPR>
+__device__ __forceinline__ int kc_swz(int r) {
+    constexpr int RPB = 16 / CPR;          // rows per 256-byte bank row
+    const int j = (r / RPB) % CPR;
+    return CPR == 4 ? ((CPR - j) & (CPR - 1)) : j;
+}
 template <int BK>
 __device__ __forceinline__ int kc_off_bf16(int r, int kc) {
     constexpr int CPR = BK / 8;            // chunks per row
-    constexpr int RPB = 16 / CPR;          // rows per 256-byte bank row
-    const int swz = (r / RPB) % CPR;
-    return r * (BK * 2) + ((kc ^ swz) << 4);
+    return r * (BK * 2) + ((kc ^ kc_swz<CPR>(r)) << 4);
 }
 // bf16, row-contiguous tile [BK][BR]: byte offset of element (k, col); 32-byte granules are XOR-ed
 // with a function of k so that the 8 k-rows one half-wave transposed read touches hit distinct banks.
@@ -697,8 +707,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
         if constexpr (!A_RC) {
             const int r = s / CPR;
             kc_row_setup<AK>(a, m0 + r, a_rows[i]);
-            constexpr int RPB = 16 / CPR;
-            a_kl[i] = ((s % CPR) ^ ((r / RPB) % CPR)) * 8;
+            a_kl[i] = ((s % CPR) ^ kc_swz<CPR>(r)) * 8;
         } else {
             const int k = s / (BM / 8);
             a_kl[i] = k;
@@ -714,8 +723,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
             b_rows[i].valid = n < a.N;
             b_rows[i].base = n * a.ldb;
             b_rows[i].hb = b_rows[i].wb = 0;
-            constexpr int RPB = 16 / CPR;
-            b_kl[i] = ((s % CPR) ^ ((r / RPB) % CPR)) * 8;
+            b_kl[i] = ((s % CPR) ^ kc_swz<CPR>(r)) * 8;
         } else {
             const int k = s / (BN / 8);
             b_kl[i] = k;
