@@ -724,7 +724,9 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const T* __restrict_
 // column stripe through its operands and the GEMM core measured 283 TFLOP/s on BERT-base shapes against 480 for
 // K-contiguous operands of the same size (tools/gemm_sweep.py).  Transposing dY and X once (HBM-bound, ~40 us for the 100 MB
 // of a BertLayer) and running the weight gradients as K-contiguous GEMMs is the faster total.
-// 64x64 tiles; LDS image of 32-bit words with a 33-word pitch (conflict-free both ways); 16-byte global accesses.
+// 64x64 tiles; LDS image of 32-bit words with a 33-word pitch, the word index XOR-ed with 4 in the lower half of the rows: the
+// read phase has rows 8k + q and 8(k + 4) + q in one 32-lane group, which a pitch alone leaves on the same bank (PMC: 40 % of
+// the LDS cycles were conflicts); 16-byte global accesses.
 // ============================================================================================
 __device__ __forceinline__ void transpose_bf16_tile(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
                                                     int R, int Cc, long long lds_, long long ldd, int bx, int by,
@@ -735,7 +737,7 @@ __device__ __forceinline__ void transpose_bf16_tile(const unsigned short* __rest
         u32x4 v = {0u, 0u, 0u, 0u};
         if (r0 + r < R && c0 + ch * 8 < Cc) v = *(const u32x4*)(src + (long long)(r0 + r) * lds_ + c0 + ch * 8);
 #pragma unroll
-        for (int w = 0; w < 4; ++w) tile[r][ch * 4 + w] = v[w];
+        for (int w = 0; w < 4; ++w) tile[r][(ch * 4 + w) ^ ((r >> 5) << 2)] = v[w];
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 512; i += 256) {
@@ -744,7 +746,7 @@ __device__ __forceinline__ void transpose_bf16_tile(const unsigned short* __rest
         unsigned e[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const unsigned w = tile[k * 8 + q][j >> 1];
+            const unsigned w = tile[k * 8 + q][(j >> 1) ^ (((k * 8 + q) >> 5) << 2)];
             e[q] = (j & 1) ? (w >> 16) : (w & 0xffffu);
         }
         const u32x4 o = {e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
