@@ -412,6 +412,14 @@ def main():
         else:
             dist.init_process_group(backend)
     batch, classes, train_tflop, desc = WORKLOADS[args.workload]
+    # a line measured with work left out is invalid: the work-skipping switch of tools/knockout.sh exists only in
+    # -DHS_MEASURE builds of the library, and this script refuses both the variable and such a build
+    if os.environ.get("HAMSPINE_KNOCKOUT", "0") not in ("", "0"):
+        sys.exit("bench.py: HAMSPINE_KNOCKOUT is set -- it removes launches from the step; refusing to produce a bench line "
+                 "(use tools/knockout.sh, which times such steps without printing one)")
+    from hamspine import _lib as _L
+    if _L.lib().hs_measure_build() and os.environ.get("HAMSPINE_ALLOW_MEASURE_BUILD") != "1":
+        sys.exit("bench.py: libhamspine_hip.so was built with -DHS_MEASURE (knockout switches compiled in); rebuild without it")
     dt, final_loss, roofline, nparams, host_ms, f32_mode = gpu_leg(args, rank, world, local_rank)
     if rank == 0:
         value = batch * world * args.steps / dt

@@ -520,6 +520,15 @@ hs_status hs_attention_bwd(const hs_attn_desc* d, const void* q, const void* k, 
 /* weight-gradient side stream inside the composites below: 1 on (default; env HAMSPINE_OVERLAP=0 turns it off),
    0 off = every kernel of a composite runs on the caller's stream (used to time kernels in isolation). */
 void hs_set_overlap(int32_t on);
+/* Gradient milestones for bucketed data-parallel exchange (reference mibf_net/train_resnet.py:134: DDP starts a bucket's
+   all-reduce when its last gradient is ready).  The NEXT hs_resnet_bwd / hs_bert_bwd on the calling thread records
+   events[i] (hipEvent_t) on its stream right after the kernels that finish the parameter gradient at grad_ptrs[i] (one of the
+   dw / db / dgamma / dbeta pointers of its descriptor) have been enqueued; entries it does not recognise are recorded when
+   it returns.  n <= 64; n = 0 clears the list. */
+hs_status hs_grad_milestones(int32_t n, const void* const* grad_ptrs, void* const* events);
+/* 1 when the library was built with -DHS_MEASURE (the HAMSPINE_KNOCKOUT work-skipping switch of tools/knockout.sh is compiled
+   in; results may be garbage when that variable is set), 0 for the release build.  bench.py refuses a measurement build. */
+int32_t hs_measure_build(void);
 /* BertLayer backward (bf16): weight gradients as K-contiguous GEMMs on transposed copies of dY and X (1, default) or straight
    from the row-major operands (0); measurement / A-B testing switch. */
 void hs_set_wgrad_nt(int32_t on);

@@ -261,6 +261,9 @@ def _declare(l):
     l.hs_gradcam.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
     l.hs_stage_images_u8.argtypes = [vp, vp, i32, i32, i32, P(f32), P(f32), vp]
     l.hs_set_overlap.restype = None
+    l.hs_grad_milestones.argtypes = [i32, P(vp), P(vp)]
+    l.hs_measure_build.argtypes = []
+    l.hs_measure_build.restype = i32
     l.hs_set_wgrad_nt.argtypes = [i32]
     l.hs_set_wgrad_nt.restype = None
     l.hs_dwconv_ws_bytes.argtypes = [i32] * 5

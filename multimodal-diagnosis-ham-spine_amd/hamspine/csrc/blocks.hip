@@ -163,14 +163,57 @@ static void run_init(Run& r, int dt, bool plan, void* saved, long long saved_byt
 // marginal cost in the overlapped schedule off the step time (results are then garbage; tools/knockout.sh).  Bits: 1 ResNet
 // weight gradients, 2 BERT weight-gradient GEMMs, 4 transposes, 8 BatchNorm forward, 16 BatchNorm backward, 64 weight casts,
 // 128 LayerNorm backward, 256 attention cores, 512 ResNet data-gradient convolutions, 1024 BERT data-gradient GEMMs.
+// The switch exists only in measurement builds (make EXTRA=-DHS_MEASURE, what tools/knockout.sh builds): a release library
+// ignores the variable, hs_measure_build() reports which one is loaded and bench.py refuses to run on a measurement build.
+#ifdef HS_MEASURE
 static int knock() {
     static const int v = [] { const char* e = getenv("HAMSPINE_KNOCKOUT"); return e ? atoi(e) : 0; }();
     return v;
 }
+#else
+static constexpr int knock() { return 0; }
+#endif
 #define CALLK(r, bit, expr)                                        \
     do {                                                           \
         if (!(r).plan && !(knock() & (bit))) HS_PROPAGATE(expr);   \
     } while (0)
+
+// ---- gradient milestones (hs_grad_milestones) ---------------------------------------------------------------------
+// A data-parallel caller that exchanges gradients bucket by bucket wants to start a bucket's exchange as soon as the LAST
+// gradient of that bucket has been enqueued -- not when the whole tower's backward has.  It hands the next tower backward on
+// this thread a list of (parameter-gradient pointer, HIP event): the executor records the event on its stream right after
+// the kernels that finish that gradient have been enqueued (BERT: at the end of the layer that owns the pointer, or after
+// the embeddings; ResNet: the weight gradients run as grouped grids behind the data-gradient chain, so all at the end).
+// Entries left over when the executor returns are recorded there, so the caller can always wait on every event.
+constexpr int kMaxMilestones = 64;
+struct Milestones {
+    int n = 0;
+    const void* ptr[kMaxMilestones];
+    hipEvent_t ev[kMaxMilestones];
+};
+static thread_local Milestones g_ms;
+static int milestones_hit(Run& r, const void* const* ptrs, int np) {     // record the events whose pointer is among ptrs
+    if (r.plan) return HS_OK;
+    for (int m = 0; m < g_ms.n;) {
+        bool hit = false;
+        for (int k = 0; k < np && !hit; ++k) hit = ptrs[k] && ptrs[k] == g_ms.ptr[m];
+        if (hit) {
+            HS_CHECK_HIP(hipEventRecord(g_ms.ev[m], r.s));
+            g_ms.ptr[m] = g_ms.ptr[g_ms.n - 1];
+            g_ms.ev[m] = g_ms.ev[g_ms.n - 1];
+            --g_ms.n;
+        } else {
+            ++m;
+        }
+    }
+    return HS_OK;
+}
+static int milestones_flush(Run& r) {                                    // record every remaining event
+    if (r.plan) return HS_OK;
+    for (int m = 0; m < g_ms.n; ++m) HS_CHECK_HIP(hipEventRecord(g_ms.ev[m], r.s));
+    g_ms.n = 0;
+    return HS_OK;
+}
 
 static hs_gemm_params gemm_defaults(int dt) {
     hs_gemm_params p;
@@ -1568,7 +1611,7 @@ static int resnet_bwd_run(Run& r, const hs_resnet_desc& d, const void* const* dy
         HS_PROPAGATE(stem_bwd_run(r, d.stem, r.saved.base ? r.saved.base + lo.y_off[0] : nullptr, dy));
         r.ws.release(wm);
     }
-    return HS_OK;
+    return milestones_flush(r);
 }
 
 // ---- BERT ----------------------------------------------------------------------------------
@@ -1632,12 +1675,17 @@ static int bert_bwd_run(Run& r, const hs_bert_desc& d, const int64_t* ids, const
         const long long wm = r.ws.mark();
         HS_PROPAGATE(bert_layer_bwd_run(r, l, base ? base + lo.y_off[i] : nullptr, dy, dx));
         r.ws.release(wm);
+        {
+            const void* gp[16] = {l.q.dw, l.q.db, l.k.dw, l.k.db, l.v.dw, l.v.db, l.ao.dw, l.ao.db, l.ln1.dgamma, l.ln1.dbeta,
+                                  l.inter_l.dw, l.inter_l.db, l.out_l.dw, l.out_l.db, l.ln2.dgamma, l.ln2.dbeta};
+            HS_PROPAGATE(milestones_hit(r, gp, 16));
+        }
         dy = dx;
         cur ^= 1;
     }
     // embeddings: dropout mask, LayerNorm backward, scatter into the tables (BertEmbeddings with token_type_ids = 0)
     const bool any = d.dword || d.dpos || d.dtype0 || d.dgamma || d.dbeta;
-    if (!any) return HS_OK;
+    if (!any) return milestones_flush(r);
     const void* g = dy;
     if (d.embed_dropout > 0.f) {
         char* gd = gbuf[cur];
@@ -1664,7 +1712,7 @@ static int bert_bwd_run(Run& r, const hs_bert_desc& d, const int64_t* ids, const
         if (!r.plan && d.n_types > 1) HS_CHECK_HIP(hipMemsetAsync(d.dtype0 + Hd, 0, (size_t)(d.n_types - 1) * Hd * 4, r.s));
         CALL(r, hs_colsum(d.dtype, dsum, M, Hd, Hd, d.dtype0, csws, csb, 0, r.s));
     }
-    return HS_OK;
+    return milestones_flush(r);
 }
 
 }  // namespace hs
@@ -2103,6 +2151,24 @@ hs_status hs_bert_bwd(const hs_bert_desc* d, const int64_t* ids, const int64_t* 
 /* weight-gradient side stream inside the composites: 1 on (default, or HAMSPINE_OVERLAP), 0 off (every kernel of a
    composite on the caller's stream, e.g. to time kernels in isolation). */
 void hs_set_overlap(int32_t on) { hs::g_overlap = on ? 1 : 0; }
+hs_status hs_grad_milestones(int32_t n, const void* const* grad_ptrs, void* const* events) {
+    HS_REQUIRE(n >= 0 && n <= kMaxMilestones, "grad_milestones: %d entries (max %d)", n, kMaxMilestones);
+    HS_REQUIRE(n == 0 || (grad_ptrs && events), "grad_milestones: null argument");
+    g_ms.n = n;
+    for (int i = 0; i < n; ++i) {
+        HS_REQUIRE(grad_ptrs[i] && events[i], "grad_milestones: null entry %d", i);
+        g_ms.ptr[i] = grad_ptrs[i];
+        g_ms.ev[i] = (hipEvent_t)events[i];
+    }
+    return HS_OK;
+}
+int32_t hs_measure_build(void) {
+#ifdef HS_MEASURE
+    return 1;
+#else
+    return 0;
+#endif
+}
 /* BertLayer weight gradients from transposed (K-contiguous) operands: 1 on (default), 0 = the row-major "tn" form. */
 void hs_set_wgrad_nt(int32_t on) { hs::g_wgrad_nt = on ? 1 : 0; }
 }

@@ -13,16 +13,31 @@ MI355X-first design
     per-link bandwidth: few, large collectives).  The HIP backward nodes write parameter gradients
     straight into the bucket (hamspine.rt.grad_arena: zero-copy, no flatten pass),
   * buckets are laid out in reverse parameter order (~ the order backward produces them); when the last
-    gradient of a bucket lands, its all-reduce is enqueued on a side HIP stream behind an event, so the
-    collective overlaps the rest of backward,
+    gradient of a bucket lands, its exchange is enqueued on a side HIP stream, so the collective overlaps the
+    rest of backward.  Buckets are always launched IN INDEX ORDER and EVERY bucket is launched every step, so all
+    ranks issue the same sequence of collectives whatever their local gradient sets look like,
+  * the whole-tower executors (hamspine.tower: one C call per tower and direction) stay on under data
+    parallelism: the tower's backward records one HIP event per bucket at the point of its stream where that
+    bucket's last gradient has been enqueued (`hs_grad_milestones`, csrc/blocks.hip), and the bucket's exchange
+    waits for THAT event, not for the tower's end -- bucket-level overlap without per-block Python nodes,
   * one wait on the side stream before optimizer.step() (`finish()`, also run automatically at the end of
     each backward through an autograd-engine callback),
   * the set of parameters that never receive a gradient (find_unused_parameters semantics: the BERT pooler,
-    MIBF's I2Iattention) is LEARNT on the first step; from the second step on a bucket counts only its used
-    parameters, so the bucket that holds the pooler (the first one in reverse order) launches during backward
-    like every other one instead of waiting for finish().  The graph is static per model configuration; if a
-    learnt-unused parameter does receive a gradient later the wrapper raises instead of silently dropping it.
+    MIBF's I2Iattention) is LEARNT on the first step and made identical on all ranks by one all-reduce of the
+    used bitmap; from the second step on a bucket counts only its used parameters, so the bucket that holds the
+    pooler launches during backward like every other one instead of waiting for finish().  If a learnt-unused
+    parameter does receive a gradient later, the wrapper re-learns: the parameter counts as used from then on
+    (this step included when its bucket has not been launched yet).  Only a gradient that arrives AFTER its
+    bucket's exchange has started cannot be honoured; that raises, naming `static_unused=False`, the mode in
+    which buckets holding not-always-used parameters wait for the end of backward (torch DDP's behaviour).
+  * exchange algorithm (`algo=`, env HAMSPINE_DDP_ALGO): "allreduce" (default: one RCCL all-reduce(AVG) of the
+    f32 bucket, the reference's semantics bit for bit in f32), "direct" (reduce-scatter as an all-to-all of
+    shards + a local f32 sum, then all-gather: on xGMI's fully connected point-to-point links both phases use all
+    7 links of a GPU at once instead of a ring) and "direct_bf16" (the same with a bf16 wire format:
+    every rank sends bf16 shards, the owner of a shard sums them in f32, the reduced shard travels back in bf16
+    -- half the bytes, f32 accumulation).
 """
+import os
 import warnings
 
 import torch
@@ -33,34 +48,46 @@ from . import rt
 
 
 class _Bucket:
-    def __init__(self, params, device):
+    def __init__(self, params, device, world):
         self.params = params
         self.offsets = []
         n = 0
         for p in params:
             self.offsets.append(n)
             n += (p.numel() + 63) // 64 * 64          # 256-byte aligned slots
-        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self.numel = n
+        pad = (-n) % (64 * max(world, 1))             # the direct algorithms cut the bucket into `world` equal shards
+        self.flat = torch.zeros(n + pad, dtype=torch.float32, device=device)
         self.views = [self.flat[o:o + p.numel()].as_strided(p.shape, p.stride()) for p, o in zip(params, self.offsets)]
         self.ready = 0
         self.have = [False] * len(params)
         self.unused = [False] * len(params)       # learnt after the first step: parameters that take no part in the step
         self.need = len(params)                   # gradients that make the bucket complete
         self.launched = False
-        self.work = None
-        self.streams = {}                         # streams this bucket's gradients became final on
+        self.work = []
+        self.streams = {}                         # streams this bucket's gradients became final on (hook time)
+        self.events = {}                          # stream id -> event recorded INSIDE a tower backward (milestones)
+        self.hook_events = {}                     # stream id -> event re-recorded by every hook on that stream
+        self.hook_sids = set()                    # streams whose hook event was recorded in this step
+        self.spare = {}                           # stream id -> reusable event objects
+        self.post = None
 
 
 class DataParallel(nn.Module):
-    def __init__(self, module, process_group=None, bucket_mb=128, broadcast_buffers=True, zero_copy=None):
+    def __init__(self, module, process_group=None, bucket_mb=128, broadcast_buffers=True, zero_copy=None, algo=None,
+                 static_unused=True):
         super().__init__()
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(self.pg) if dist.is_initialized() else 0
         self.broadcast_buffers = broadcast_buffers
+        self.static_unused = bool(static_unused)
         params = [p for p in module.parameters() if p.requires_grad]
         self.device = params[0].device
         self.on_gpu = self.device.type == "cuda"
+        # a collective group exists (possibly of one rank: bench.py --ddp-config runs the whole exchange path at N = 1)
+        self.collective = dist.is_initialized() and (self.world > 1 or os.environ.get("HAMSPINE_DDP_SINGLE") == "1")
         # rank 0's parameters / buffers win (DDP constructor semantics)
         if self.world > 1:
             for t in list(module.parameters()) + list(module.buffers()):
@@ -70,12 +97,12 @@ class DataParallel(nn.Module):
         self.buckets, cur, cur_n = [], [], 0
         for p in reversed(params):
             if cur and cur_n + p.numel() > cap:
-                self.buckets.append(_Bucket(cur, self.device))
+                self.buckets.append(_Bucket(cur, self.device, self.world))
                 cur, cur_n = [], 0
             cur.append(p)
             cur_n += p.numel()
         if cur:
-            self.buckets.append(_Bucket(cur, self.device))
+            self.buckets.append(_Bucket(cur, self.device, self.world))
         # zero-copy bucketing (backward nodes write d(param) straight into the bucket slot) needs every parameter to be
         # used ONCE per step: a model that runs a tower twice (gate / global-local, reference model.py:257-281,334-337)
         # produces two gradients per parameter which autograd sums before AccumulateGrad runs -- both would land in the
@@ -84,9 +111,11 @@ class DataParallel(nn.Module):
             zero_copy = not (getattr(module, "gate_enabled", False) or getattr(module, "global_local_enabled", False))
         self.zero_copy = bool(zero_copy)
         self._where = {}
+        self._order = []                              # (bucket, index) in bucket order: the layout of the used bitmap
         for b in self.buckets:
             for i, p in enumerate(b.params):
                 self._where[p] = (b, i)
+                self._order.append((b, i))
                 if self.zero_copy:
                     rt.grad_arena_register(p, b.views[i])
                 p.register_post_accumulate_grad_hook(self._on_grad)
@@ -97,9 +126,17 @@ class DataParallel(nn.Module):
         self._callback_queued = False
         self._dirty = False
         self._learnt_unused = False
+        self._next = 0                                # index of the next bucket to launch (launches are in order)
+        self._covered = set()                         # ids of parameters whose gradients a tower milestone covers (this step)
         self.stats = {"launched_in_backward": 0, "launched_in_finish": 0}   # how many bucket collectives overlapped backward
-        nccl = self.world > 1 and dist.get_backend(self.pg) == "nccl"     # AVG exists in RCCL only; gloo sums, then / world
+        backend = dist.get_backend(self.pg) if dist.is_initialized() else None
+        nccl = backend == "nccl"                      # AVG exists in RCCL only; gloo sums, then / world
         self._avg_op = dist.ReduceOp.AVG if (self.on_gpu and nccl) else dist.ReduceOp.SUM
+        self.algo = algo or os.environ.get("HAMSPINE_DDP_ALGO", "allreduce")
+        if self.algo not in ("allreduce", "direct", "direct_bf16"):
+            raise ValueError(f"hamspine.ddp: unknown exchange algorithm {self.algo!r}")
+        if self.on_gpu and self.zero_copy:
+            rt.add_milestone_provider(self)
 
     # ------------------------------------------------------------------------------------------
     def sync_buffers(self):
@@ -119,16 +156,59 @@ class DataParallel(nn.Module):
             self.sync_buffers()
         return super().train(mode)
 
+    # ---- milestones: called by hamspine.tower around a whole-tower backward --------------------------------------------
+    def _event(self, b, sid):
+        pool = b.spare.setdefault(sid, [])
+        return pool.pop() if pool else torch.cuda.Event()
+
+    def _milestones(self, params, stream):
+        """`params`: a tower's parameters in the order its backward FINISHES their gradients last-to-first reversed, i.e.
+        params[0]'s gradient is produced last (hamspine.tower passes bert_params: embeddings first, layer 0, 1, ...; the
+        backward walks the layers from the top down).  Returns [(index into params, event handle, key)]: for every bucket
+        holding some of these parameters, the member whose gradient is enqueued LAST and the event the executor records
+        right after it."""
+        first = {}
+        for i, p in enumerate(params):
+            w = self._where.get(p)
+            if w is None:
+                continue
+            self._covered.add(id(p))                  # its position in the stream is covered by a milestone, not by a hook event
+            b, k = w
+            if b.unused[k] or id(b) in first:
+                continue
+            first[id(b)] = (i, b)
+        out = []
+        sid = stream.cuda_stream
+        for i, b in first.values():
+            ev = self._event(b, sid)
+            ev.record(stream)                         # creates the HIP event (torch creates it lazily); re-recorded by the executor
+            out.append((i, ev.cuda_event, (b, sid, ev)))
+        return out
+
+    def _milestones_recorded(self, keys):
+        for b, sid, ev in keys:
+            old = b.events.get(sid)
+            if old is not None:
+                b.spare[sid].append(old)
+            b.events[sid] = ev
+
+    # ---- hooks ---------------------------------------------------------------------------------------------------------
     def _on_grad(self, p):
         """post-accumulate hook (autograd thread; the AccumulateGrad node's stream is current and already ordered
         behind the node that produced the gradient)"""
         b, i = self._where[p]
-        if b.unused[i]:
-            raise RuntimeError("hamspine.ddp: a parameter that received no gradient on the first step received one now; "
-                               "the unused-parameter set is learnt once (static graph per model configuration)")
         if b.launched:
+            if b.unused[i]:
+                raise RuntimeError(
+                    "hamspine.ddp: a parameter that took no part in the first step received a gradient after its bucket's "
+                    "exchange had started in this step.  The set of used parameters changes from step to step in this model: "
+                    "construct DataParallel(..., static_unused=False) so that buckets holding such parameters wait for the end "
+                    "of backward")
             raise RuntimeError("hamspine.ddp: a gradient arrived after its bucket's all-reduce was launched (a second "
                                "backward() before finish()/optimizer.step(): gradient accumulation is not supported)")
+        if b.unused[i]:                                      # the used set grew: count it from now on (re-learn)
+            b.unused[i] = False
+            b.need += 1
         view = b.views[i]
         if p.grad.data_ptr() != view.data_ptr():             # gradient produced outside the arena: copy once
             view.copy_(p.grad)
@@ -136,7 +216,14 @@ class DataParallel(nn.Module):
         self._dirty = True
         if self.on_gpu:
             s = torch.cuda.current_stream(self.device)
-            b.streams[s.cuda_stream] = s
+            sid = s.cuda_stream
+            b.streams[sid] = s
+            if id(p) not in self._covered:                   # not a tower-milestone gradient: mark its position in the stream
+                ev = b.hook_events.get(sid)
+                if ev is None:
+                    ev = b.hook_events[sid] = self._event(b, sid)
+                ev.record(s)
+                b.hook_sids.add(sid)
         if not b.have[i]:
             b.have[i] = True
             b.ready += 1
@@ -144,61 +231,126 @@ class DataParallel(nn.Module):
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
             self._callback_queued = True
         # (a parameter used several times in one step still fires this hook once: autograd sums its gradients first)
-        if b.ready == b.need and not b.launched:
-            self.stats["launched_in_backward"] += 1
+        self._launch_ready(in_backward=True)
+
+    def _complete(self, b):
+        if b.ready < b.need:
+            return False
+        # static_unused=False: a bucket that holds parameters which are not used in every step cannot know during backward
+        # whether they will still arrive
+        return self.static_unused or b.need == len(b.params)
+
+    def _launch_ready(self, in_backward):
+        """launch, in index order, every bucket that is complete (in finish(): every remaining bucket)"""
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            if in_backward:
+                # before the unused set is known a bucket is complete when ALL its parameters have arrived
+                ok = self._complete(b) if self._learnt_unused else b.ready == len(b.params)
+                if not ok:
+                    return
+            self.stats["launched_in_backward" if in_backward else "launched_in_finish"] += 1
             self._launch(b)
+            self._next += 1
 
     def _launch(self, b):
         b.launched = True
-        if self.world == 1:
+        if not self.collective:
             return
+        absent = [i for i, got in enumerate(b.have) if not got]
         if self.on_gpu:
-            # order the collective behind EVERY stream one of the bucket's gradients became final on (the two towers run
-            # on different streams), not just the stream of the hook that completed the bucket
-            streams, b.streams = b.streams, {}
-            cur = torch.cuda.current_stream(self.device)
-            streams[cur.cuda_stream] = cur
-            for s in streams.values():
-                self.comm_stream.wait_stream(s)
+            # order the exchange behind the point of EVERY stream where this bucket's last gradient was enqueued: the tower
+            # milestone event where a tower's backward recorded one, and the event the hooks of other parameters left
+            for sid, ev in b.events.items():
+                self.comm_stream.wait_event(ev)
+            for sid in b.hook_sids:
+                self.comm_stream.wait_event(b.hook_events[sid])
+            for sid, st in b.streams.items():
+                if sid not in b.events and sid not in b.hook_sids:
+                    self.comm_stream.wait_stream(st)
+            if not b.events and not b.hook_sids:             # no gradient here at all: still behind the last step's readers
+                self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm_stream):
-                b.work = dist.all_reduce(b.flat, op=self._avg_op, group=self.pg, async_op=True)
+                for i in absent:
+                    b.views[i].zero_()                       # absent here (unused, or used on another rank only): contributes zeros
+                self._exchange(b)
         else:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            for i in absent:
+                b.views[i].zero_()
+            self._exchange(b)
+
+    def _exchange(self, b):
+        """average b.flat over the ranks (asynchronously where the backend allows)"""
+        W = self.world
+        if self.algo == "allreduce":
+            b.work.append(dist.all_reduce(b.flat, op=self._avg_op, group=self.pg, async_op=True))
+            b.post = "div" if self._avg_op == dist.ReduceOp.SUM and W > 1 else None
+            return
+        # "direct": every rank sends shard r of its bucket to rank r (all-to-all: on xGMI's fully connected point-to-point
+        # links a GPU drives its 7 links at once), the owner sums the W copies of its shard in f32, and the reduced shards
+        # travel back (all-gather).  "direct_bf16": the same with bf16 on the wire -- half the bytes, f32 accumulation.
+        wire = torch.bfloat16 if self.algo == "direct_bf16" else torch.float32
+        shard = b.flat.numel() // W
+        send = b.flat.to(wire) if wire != torch.float32 else b.flat
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.pg)            # recv[r * shard:(r + 1) * shard] = rank r's copy of MY shard
+        red = recv.view(W, shard).float().sum(0).div_(W).to(wire)
+        if wire == torch.float32:
+            dist.all_gather_into_tensor(b.flat, red, group=self.pg)
+        else:
+            out = torch.empty(W * shard, dtype=wire, device=b.flat.device)
+            dist.all_gather_into_tensor(out, red, group=self.pg)
+            b.flat.copy_(out)
+        b.post = None
+
+    def _learn(self):
+        """first step: who takes part in the step -- the union over ranks (one all-reduce of the used bitmap), so that every
+        rank counts the same parameters and launches its buckets at matching points"""
+        flags = torch.tensor([1 if b.have[i] else 0 for b, i in self._order], dtype=torch.int32)
+        if self.world > 1:
+            dev = flags.to(self.device) if (self.on_gpu and dist.get_backend(self.pg) == "nccl") else flags
+            dist.all_reduce(dev, op=dist.ReduceOp.MAX, group=self.pg)
+            flags = dev.cpu()
+        used = flags.tolist()
+        for (b, i), u in zip(self._order, used):
+            b.unused[i] = not u
+        for b in self.buckets:
+            b.need = sum(1 for u in b.unused if not u)
+        self._learnt_unused = True
 
     def finish(self):
-        """Reduce the buckets that never filled (unused parameters) and wait for all collectives.  Called by
-        the autograd engine at the end of backward; safe to call again before optimizer.step()."""
+        """Launch the buckets that did not complete during backward (unused parameters) and wait for all exchanges.
+        Called by the autograd engine at the end of backward; safe to call again before optimizer.step()."""
         self._callback_queued = False
         if not self._dirty:
             return
         self._dirty = False
+        self._launch_ready(in_backward=False)
         for b in self.buckets:
-            if not b.launched and b.ready > 0:
-                for i, got in enumerate(b.have):
-                    if not got:
-                        b.views[i].zero_()                   # absent on every rank alike: contributes zeros
-                self.stats["launched_in_finish"] += 1
-                self._launch(b)
-        for b in self.buckets:
-            if b.work is not None:
-                b.work.wait()
-                b.work = None
-                if self._avg_op == dist.ReduceOp.SUM and self.world > 1:
-                    b.flat.div_(self.world)
-        if self.on_gpu and self.world > 1:
+            for w in b.work:
+                w.wait()
+            if b.work and b.post == "div":
+                b.flat.div_(self.world)
+            b.work = []
+        if self.on_gpu and self.collective:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        first = not self._learnt_unused
+        if first:
+            self._learn()
         for b in self.buckets:
             for i, p in enumerate(b.params):
                 if not b.have[i] and p.grad is not None and p.grad.data_ptr() == b.views[i].data_ptr():
                     p.grad = None                            # unused this step: keep DDP's grad=None contract
-            if not self._learnt_unused:                      # first step: learn who takes part (see module docstring)
-                b.unused = [not h for h in b.have]
-                b.need = sum(b.have)
             b.ready = 0
             b.have = [False] * len(b.params)
             b.launched = False
             b.streams = {}
-        self._learnt_unused = True
+            b.hook_sids = set()
+            for sid, ev in b.events.items():
+                b.spare.setdefault(sid, []).append(ev)
+            b.events = {}
+        self._covered = set()
+        self._next = 0
 
     def zero_grad(self, set_to_none=True):
         self.module.zero_grad(set_to_none=set_to_none)

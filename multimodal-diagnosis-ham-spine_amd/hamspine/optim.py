@@ -13,7 +13,14 @@ from . import rt
 
 
 import os as _os
-_KNOCK_ADAM = int(_os.environ.get("HAMSPINE_KNOCKOUT", "0")) & 32 != 0     # measurement only: see csrc/blocks.hip knock()
+def _knock_adam():
+    """measurement only (tools/knockout.sh): honoured only by a library built with -DHS_MEASURE, see csrc/blocks.hip knock()"""
+    if not int(_os.environ.get("HAMSPINE_KNOCKOUT", "0")) & 32:
+        return False
+    return bool(L.lib().hs_measure_build())
+
+
+_KNOCK_ADAM = None
 
 
 class _FusedAdamBase(torch.optim.Optimizer):
@@ -113,6 +120,9 @@ class _FusedAdamBase(torch.optim.Optimizer):
         per-tensor checks -- is built once per parameter set, the step counter is ONE shared 0-dim tensor per chunk
         (state[p]["step"] of every tensor in it), and the gradient pointer table is rebuilt only when a gradient pointer
         changed (the tower executors and hamspine.ddp hand out the same gradient memory every step)."""
+        global _KNOCK_ADAM
+        if _KNOCK_ADAM is None:
+            _KNOCK_ADAM = _knock_adam()
         if not ps or _KNOCK_ADAM:
             return
         lib = L.lib()
@@ -162,7 +172,13 @@ class _FusedAdamBase(torch.optim.Optimizer):
                         p.grad = g2
                 gptrs = [p.grad.data_ptr() for p in sel]
                 ch["gptrs"], ch["garr"] = gptrs, (C.c_void_p * n)(*gptrs)
-            if self.state[sel[0]]["step"] is not ch["step"]:   # load_state_dict replaced the counters
+            # Every tensor of the chunk must still share THIS chunk's counter object.  load_state_dict replaces the counters;
+            # so does another table of the same group built for a different set of parameters-with-gradients (an unused
+            # parameter, an expert without tokens, set_to_none): it rebinds state[p]["step"] of its own subset, and a check of
+            # the first tensor alone would let this table's stale step_host through for the rest.  On a mismatch the table
+            # is rebuilt from the per-parameter counters (by_step above), which keeps torch.optim's per-parameter step count.
+            st_all = self.state
+            if any(st_all[p]["step"] is not ch["step"] for p in sel):
                 cache.pop(key, None)
                 return self._update(group, ps, grad_scale)
             ch["step_host"] += 1

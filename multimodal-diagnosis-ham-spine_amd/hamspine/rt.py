@@ -112,6 +112,36 @@ def arena_version():
     return _arena_version[0]
 
 
+# Gradient milestones (hamspine.ddp <-> hamspine.tower).  A data-parallel wrapper that owns bucket slots registers itself
+# here; a whole-tower backward asks, before its one C call, which of its parameters is the LAST one of each bucket to be
+# produced, hands (gradient pointer, HIP event) pairs to the executor (hs_grad_milestones) and reports afterwards that
+# the events have been recorded on its stream.
+import weakref as _weakref
+
+_milestone_providers = []
+
+
+def add_milestone_provider(obj):
+    """obj: has _milestones(params, stream) -> [(index, raw event handle, key)] and _milestones_recorded(keys)"""
+    _milestone_providers.append(_weakref.ref(obj))
+
+
+def grad_milestones(params, stream):
+    """-> [(provider, [(index into params, raw HIP event handle, key)])] over the live data-parallel wrappers"""
+    out = []
+    live = []
+    for r in _milestone_providers:
+        o = r()
+        if o is None:
+            continue
+        live.append(r)
+        ms = o._milestones(params, stream)
+        if ms:
+            out.append((o, ms))
+    _milestone_providers[:] = live
+    return out
+
+
 def grad_buffer_like(param):
     """Where a backward node writes d(param): the bucket slot when data-parallel training registered one
     (zero-copy bucketing), else a fresh tensor laid out like the parameter."""

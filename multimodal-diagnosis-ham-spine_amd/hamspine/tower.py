@@ -46,17 +46,33 @@ def _has_hooks(root):
 
 
 def towers_enabled():
-    """One node per tower needs no gradient exchange DURING the tower's backward: under data parallelism (hamspine.ddp or
-    torch's DistributedDataParallel, reference mibf_net/train_resnet.py:134) the per-block nodes stay, because their
-    parameter gradients become final -- and their buckets' all-reduces start -- layer by layer while the rest of the
-    backward still runs; a one-node tower would release all of its gradients at its end."""
+    """The whole-tower nodes are the default everywhere, data parallelism included: hamspine.ddp gets one HIP event per
+    gradient bucket from inside the tower's backward (hs_grad_milestones), so a bucket's exchange starts behind its own last
+    gradient while the rest of the tower still runs; under torch's DistributedDataParallel (reference
+    mibf_net/train_resnet.py:134) the tower's gradients become ready together at its end, which costs overlap, not
+    correctness.  HAMSPINE_TOWER_EXEC=0 selects the per-block nodes."""
     import os
-    if os.environ.get("HAMSPINE_TOWER_EXEC", "1") == "0":
-        return False
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return os.environ.get("HAMSPINE_TOWER_EXEC") == "force"
-    return True
+    return os.environ.get("HAMSPINE_TOWER_EXEC", "1") != "0"
+
+
+def _with_milestones(ent, params, call):
+    """run `call()` (one hs_*_bwd) with the data-parallel wrappers' bucket milestones registered: each gets the event of
+    every bucket recorded at the point of this stream where that bucket's last gradient has been enqueued"""
+    stream = torch.cuda.current_stream()
+    asked = rt.grad_milestones(params, stream) if ent.store is None else []
+    flat = [(ent.grad_ptrs[i], ev) for _, ms in asked for i, ev, _ in ms if ent.grad_ptrs[i]]
+    lib = L.lib()
+    if flat:
+        n = len(flat)
+        L.check(lib.hs_grad_milestones(n, (C.c_void_p * n)(*[q for q, _ in flat]), (C.c_void_p * n)(*[e for _, e in flat])),
+                "hs_grad_milestones")
+    try:
+        call()
+    finally:
+        if flat:
+            lib.hs_grad_milestones(0, None, None)
+    for o, ms in asked:
+        o._milestones_recorded([k for _, _, k in ms])
 
 
 class _GradStore:
@@ -132,6 +148,7 @@ class _ResnetEntry:
         if len(blocks) > L.RESNET_MAX_BLOCKS:
             raise L.HamspineError(f"hamspine.tower: {len(blocks)} residual blocks (max {L.RESNET_MAX_BLOCKS})")
         self.store, gp, self.make_views = _param_grad_ptrs(params, needs, device)
+        self.grad_ptrs = gp
         self.param_ptrs = [p.data_ptr() for p in params]
         d = L.ResnetDesc()
         N, _, H, W = x_shape
@@ -271,8 +288,14 @@ class ResNetTowerFn(Function):
         if _shared_buffer_unsafe(ent, params):      # one-off private gradient buffers for this backward
             desc, views = _resnet_desc_with_fresh_grads(ent, params, tuple(ctx.needs_input_grad[2:]), saved.device)
         ws = rt.workspace(int(ent.plan.ws_bytes), saved.device)
-        L.check(L.lib().hs_resnet_bwd(C.byref(desc), ptrs, saved.data_ptr(), saved.numel(), ws.data_ptr(), ws.numel(),
-                                      rt.stream()), "hs_resnet_bwd")
+
+        def call():
+            L.check(L.lib().hs_resnet_bwd(C.byref(desc), ptrs, saved.data_ptr(), saved.numel(), ws.data_ptr(), ws.numel(),
+                                          rt.stream()), "hs_resnet_bwd")
+        if desc is ent.desc:
+            _with_milestones(ent, params, call)
+        else:
+            call()
         ctx.saved_buf = None
         if ctx.counted is not None:
             ctx.counted.finish()
@@ -344,6 +367,7 @@ class _BertEntry:
         if len(model.encoder.layer) > L.BERT_MAX_LAYERS:
             raise L.HamspineError(f"hamspine.tower: {len(model.encoder.layer)} BertLayers (max {L.BERT_MAX_LAYERS})")
         self.store, gp, self.make_views = _param_grad_ptrs(params, needs, device)
+        self.grad_ptrs = gp
         self.param_ptrs = [p.data_ptr() for p in params]
         d = L.BertDesc()
         hd = rt.hs_dtype(dtype)
@@ -447,8 +471,14 @@ class BertTowerFn(Function):
             desc, views = _bert_desc_with_fresh_grads(ent, params, tuple(ctx.needs_input_grad[3:]), saved.device)
         desc.seed = ctx.seed
         ws = rt.workspace(ent.ws_bytes, saved.device)
-        L.check(L.lib().hs_bert_bwd(C.byref(desc), ctx.ids.data_ptr(), rt.p(ctx.mask), dy.data_ptr(), saved.data_ptr(),
-                                    saved.numel(), ws.data_ptr(), ws.numel(), rt.stream()), "hs_bert_bwd")
+
+        def call():
+            L.check(L.lib().hs_bert_bwd(C.byref(desc), ctx.ids.data_ptr(), rt.p(ctx.mask), dy.data_ptr(), saved.data_ptr(),
+                                        saved.numel(), ws.data_ptr(), ws.numel(), rt.stream()), "hs_bert_bwd")
+        if desc is ent.desc:
+            _with_milestones(ent, params, call)       # bert_params order: the backward finishes params[0] (embeddings) last
+        else:
+            call()
         ctx.saved_buf = None
         if ctx.counted is not None:
             ctx.counted.finish()

@@ -21,6 +21,22 @@ class _Net(nn.Module):
         return self.b(torch.relu(self.bn(self.a(x))))
 
 
+class _Branchy(nn.Module):
+    """`extra` takes part only when the caller asks for it: the set of used parameters changes from step to step.  It sits
+    at the END of the parameter list = the front of the (reverse-order) bucket, and its gradient is produced FIRST in
+    backward (it is applied to the output), so a re-learn meets a bucket that has not been launched yet."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(16, 32)
+        self.b = nn.Linear(32, 8)
+        self.extra = nn.Linear(8, 8)
+
+    def forward(self, x, branch=False):
+        y = self.b(torch.relu(self.a(x)))
+        return self.extra(y) if branch else y
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -84,9 +100,79 @@ def _worker(rank, world, port, out):
             dist.all_gather(g, ref.a.weight.grad)
             assert torch.allclose(net2.a.weight.grad, sum(g) / world, rtol=1e-5, atol=1e-6), f"big bucket step {step}"
             assert big.stats == {"launched_in_backward": step, "launched_in_finish": 1}, (step, big.stats)
+        # ---- the xGMI-native exchange algorithms: all-to-all of shards + f32 sum at the owner + all-gather --------------
+        for algo, tol in (("direct", 1e-6), ("direct_bf16", 1e-2)):
+            net3 = _Net()
+            d3 = DataParallel(net3, bucket_mb=0.001, algo=algo)
+            for step in range(2):
+                x = torch.randn(6, 16, generator=torch.Generator().manual_seed(90 + 7 * step + rank))
+                ref = _Net()
+                ref.load_state_dict(net3.state_dict())
+                ref(x).square().sum().backward()
+                d3.zero_grad()
+                d3(x).square().sum().backward()
+                d3.finish()
+                assert net3.unused.weight.grad is None
+                for (n, p), (_, q) in zip(net3.named_parameters(), ref.named_parameters()):
+                    if n.startswith("unused"):
+                        continue
+                    g = [torch.empty_like(q.grad) for _ in range(world)]
+                    dist.all_gather(g, q.grad)
+                    want = sum(g) / world
+                    err = (p.grad - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
+                    assert err <= tol, f"{algo}: {n} step {step}: rel err {err:.2e}"
+            # every rank ends with the same averaged gradient (bitwise: they all received the same reduced shards)
+            g = [torch.empty_like(net3.a.weight.grad) for _ in range(world)]
+            dist.all_gather(g, net3.a.weight.grad)
+            assert all(torch.equal(g[0], t) for t in g), f"{algo}: ranks disagree on the averaged gradient"
+        # ---- the used set changes after the first step (round-2 advisor finding) ---------------------------------------
+        # rank 1 alone runs the optional branch in step 0: the learnt set is the UNION over ranks, so rank 0 keeps
+        # contributing zeros for it and both ranks launch the same buckets at the same points
+        net4 = _Branchy()
+        d4 = DataParallel(net4, bucket_mb=128)
+        for step, branch in enumerate([rank == 1, False, True, False]):
+            x = torch.randn(6, 16, generator=torch.Generator().manual_seed(130 + 7 * step + rank))
+            ref = _Branchy()
+            ref.load_state_dict(net4.state_dict())
+            ref(x, branch).square().sum().backward()
+            d4.zero_grad()
+            d4(x, branch).square().sum().backward()
+            d4.finish()
+            flags = [torch.zeros(1) for _ in range(world)]
+            dist.all_gather(flags, torch.tensor([1.0 if branch else 0.0]))
+            for (n, p), (_, q) in zip(net4.named_parameters(), ref.named_parameters()):
+                loc = q.grad if q.grad is not None else torch.zeros_like(q)
+                g = [torch.empty_like(loc) for _ in range(world)]
+                dist.all_gather(g, loc)
+                if p.grad is None:
+                    assert q.grad is None, f"branchy step {step}: {n} lost its gradient"
+                    continue
+                assert torch.allclose(p.grad, sum(g) / world, rtol=1e-5, atol=1e-6), f"branchy {n} step {step}"
+        # a model whose optional branch first runs AFTER the first step: the wrapper re-learns instead of raising as long as
+        # the bucket has not been launched; with static_unused=False that is guaranteed (buckets holding such parameters
+        # wait for the end of backward)
+        for static in (False, True):
+            net5 = _Branchy()
+            d5 = DataParallel(net5, bucket_mb=128, static_unused=static)
+            for step, branch in enumerate([False, True, False, True]):
+                x = torch.randn(6, 16, generator=torch.Generator().manual_seed(170 + 7 * step + rank))
+                ref = _Branchy()
+                ref.load_state_dict(net5.state_dict())
+                ref(x, branch).square().sum().backward()
+                d5.zero_grad()
+                d5(x, branch).square().sum().backward()
+                d5.finish()
+                for (n, p), (_, q) in zip(net5.named_parameters(), ref.named_parameters()):
+                    if q.grad is None:
+                        assert p.grad is None, f"static={static} step {step}: {n} must keep grad None"
+                        continue
+                    g = [torch.empty_like(q.grad) for _ in range(world)]
+                    dist.all_gather(g, q.grad)
+                    assert torch.allclose(p.grad, sum(g) / world, rtol=1e-5, atol=1e-6), f"static={static} {n} step {step}"
         out.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
-        out.put((rank, repr(e)))
+        import traceback
+        out.put((rank, repr(e) + "\n" + traceback.format_exc()))
     finally:
         dist.destroy_process_group()
 

@@ -474,6 +474,37 @@ def test_fused_adamw_matches_torch():
         _close(q, r, "adamw param", 1e-5, 1e-6)
 
 
+def test_fused_adamw_counts_steps_per_parameter_when_the_gradient_set_changes():
+    """torch.optim.AdamW (reference scripts/train.py:257) counts steps per parameter: a tensor whose gradient is None in
+    some steps (an unused parameter, a MoE expert without tokens, set_to_none) takes fewer updates and must get ITS
+    bias-correction step.  The fused optimizer shares one counter per chunk and caches pointer tables per gradient set;
+    alternating sets used to let a stale counter through (round-2 advisor finding)."""
+    from hamspine.optim import FusedAdamW
+    g = torch.Generator().manual_seed(5)
+    ps = [torch.randn(s, generator=g) for s in ((40, 9), (17,), (8, 3, 3, 3), (33,))]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    got = [p.clone().to(DEV).requires_grad_(True) for p in ps]
+    o_ref = torch.optim.AdamW(ref, lr=1e-2, weight_decay=0.05)
+    o_got = FusedAdamW(got, lr=1e-2, weight_decay=0.05)
+    # step pattern: all, subset A (first tensor absent), all, subset B (last two absent), all, subset A, all
+    absent = [(), (0,), (), (2, 3), (), (0,), ()]
+    for miss in absent:
+        for i, (r, q) in enumerate(zip(ref, got)):
+            if i in miss:
+                r.grad = None
+                q.grad = None
+            else:
+                gr = torch.randn(r.shape, generator=g)
+                r.grad = gr.clone()
+                q.grad = gr.to(DEV)
+        o_ref.step()
+        o_got.step()
+    for i, (r, q) in enumerate(zip(ref, got)):
+        _close(q, r, f"adamw param {i} after alternating gradient sets", 1e-5, 1e-6)
+        assert int(o_got.state[q]["step"]) == int(o_ref.state[r]["step"]), f"step count of param {i}"
+    assert [int(o_got.state_dict()["state"][i]["step"]) for i in range(4)] == [5, 7, 6, 6]
+
+
 @pytest.mark.parametrize("kind,layers,bi", [("lstm", 1, True), ("lstm", 2, False), ("gru", 1, True), ("gru", 2, True),
                                             ("transformer", 2, True)])
 def test_sequence_encoder_matches_oracle(kind, layers, bi):
