@@ -327,7 +327,63 @@ def gpu_leg(args, rank, world, local_rank):
                     "parity": "logits <= 1e-4 * max|ref| of the CPU reference at this size (tests/test_fullsize_gpu.py)"}
         hamspine.set_compute_dtype("bf16")
         log(f"f32 mode: {d32 * 1e3:.2f} ms/step")
-    return dt, final_loss, roofline, nparams, host_ms, f32_mode
+    # ---- the N>1 configuration on this one GPU (N = 1 only): hamspine.ddp around the same model with a one-rank RCCL group,
+    # so the bucket hooks, the tower milestones, the side stream and a real `all_reduce(AVG, async_op=True)` per bucket all
+    # run; the step time is the per-rank cost of the data-parallel step minus the wire time --------------------------------
+    ddp_cfg = None
+    if world == 1 and ddp is None and not args.no_ddp_config:
+        try:
+            ddp_cfg = ddp_config_leg(net, fwd_loss, make_opt, device, batch, min(args.steps, 10))
+        except Exception as e:      # noqa: BLE001  (reported in the line, never fatal for the headline)
+            ddp_cfg = {"error": repr(e)}
+            log(f"ddp-config leg failed: {e!r}")
+    return dt, final_loss, roofline, nparams, host_ms, f32_mode, ddp_cfg
+
+
+def ddp_config_leg(net, fwd_loss, make_opt, device, batch, steps):
+    from hamspine.ddp import DataParallel
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29731")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        created = True
+    os.environ["HAMSPINE_DDP_SINGLE"] = "1"
+    try:
+        out = {}
+        for algo in ("allreduce", "direct_bf16"):
+            ddp = DataParallel(net, algo=algo)
+            opt = make_opt()
+
+            def step():
+                opt.zero_grad(set_to_none=True)
+                loss = fwd_loss()
+                loss.backward()
+                ddp.finish()
+                opt.step()
+                return loss
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = step()
+            torch.cuda.synchronize()
+            d = (time.perf_counter() - t0) / steps
+            out[algo] = {"ms_per_step": round(d * 1e3, 3), "images_per_s": round(batch / d, 1), "loss": round(loss.item(), 4),
+                         "bucket_exchanges_in_backward": ddp.stats["launched_in_backward"],
+                         "bucket_exchanges_in_finish": ddp.stats["launched_in_finish"], "buckets": len(ddp.buckets),
+                         "bucket_mb": [round(b.flat.numel() * 4 / 2**20, 1) for b in ddp.buckets]}
+            log(f"ddp-config [{algo}]: {d * 1e3:.2f} ms/step, exchanges in backward / in finish(): {ddp.stats}")
+            ddp.detach()                             # hooks and bucket slots of this wrapper go away before the next one
+            del ddp, opt
+        out["backend"] = "nccl (RCCL), world size 1: every collective of the N>1 step is issued; wire time is not represented"
+        out["steps"] = steps
+        return out
+    finally:
+        os.environ.pop("HAMSPINE_DDP_SINGLE", None)
+        if created:
+            dist.destroy_process_group()
 
 
 def cpu_leg(workload, steps=3):
@@ -396,6 +452,7 @@ def main():
     ap.add_argument("--gemm-log", default=None, help="copy the per-launch CSV of the roofline leg to this file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-f32 mode leg")
+    ap.add_argument("--no-ddp-config", action="store_true", help="skip the N=1 leg that runs the data-parallel configuration")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -420,7 +477,7 @@ def main():
     from hamspine import _lib as _L
     if _L.lib().hs_measure_build() and os.environ.get("HAMSPINE_ALLOW_MEASURE_BUILD") != "1":
         sys.exit("bench.py: libhamspine_hip.so was built with -DHS_MEASURE (knockout switches compiled in); rebuild without it")
-    dt, final_loss, roofline, nparams, host_ms, f32_mode = gpu_leg(args, rank, world, local_rank)
+    dt, final_loss, roofline, nparams, host_ms, f32_mode, ddp_cfg = gpu_leg(args, rank, world, local_rank)
     if rank == 0:
         value = batch * world * args.steps / dt
         ms_step = dt / args.steps * 1e3
@@ -441,6 +498,8 @@ def main():
         }
         if f32_mode is not None:
             out["f32_mode"] = f32_mode
+        if ddp_cfg is not None:
+            out["ddp_config"] = ddp_cfg
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle (bounded sample) ...")
             out["cpu_baseline"] = cpu_leg(args.workload)

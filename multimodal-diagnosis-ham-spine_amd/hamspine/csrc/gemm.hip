@@ -7,6 +7,7 @@
 #include <map>
 #include <tuple>
 #include "gemm_launch.h"
+#include "gemm_p8.h"
 
 namespace hs {
 
@@ -100,6 +101,16 @@ static int combo_of(int ak, int bk) {
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 static bool batch_is_one(const hs_gemm_params* p) { return p->batch <= 1; }
+// the phase-pipelined body (gemm_p8.h) for the shapes it wins on; HAMSPINE_P8=0 keeps every GEMM on the generic body
+static bool p8_enabled() {
+    static const bool on = [] { const char* e = getenv("HAMSPINE_P8"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static int p8_cfg(const hs_gemm_params* p) {
+    // 256 x 256 tiles where they give the chip enough workgroups (BERT-base at 4096 tokens: N = 2304 / 3072 -> 144 / 192)
+    if (p->M % 256 == 0 && p->N % 256 == 0 && (long long)(p->M / 256) * (p->N / 256) >= 128) return CFG_P8_256;
+    return -1;
+}
 // tile choice for everything but the stem (see the comment at the call site)
 static int auto_cfg(const hs_gemm_params* p, bool vec) {
     const long long z = (long long)(p->batch > 0 ? p->batch : 1) * (p->split_k > 1 ? p->split_k : 1);
@@ -319,12 +330,30 @@ static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q
     if (g_dbg_cfg >= 0 && g_dbg_cfg <= CFG_64x64 && cfg != CFG_STEM) cfg = g_dbg_cfg;
     if (g_dbg_cfg >= CFG_256x128 && g_dbg_cfg <= CFG_256x128x32 && bf16 && !conv) cfg = g_dbg_cfg;
     if (cfg == CFG_128x128x32 && split > 1) cfg = CFG_128x128;      // the three-workgroups-per-CU kernel has no split-K code
+    // The phase-pipelined body (gemm_p8.h): plain nt GEMMs whose tiles are all full, no split / batch / statistics riders, and
+    // an epilogue feature set it has code for.  Which of its tiles (if any) a shape takes: p8_cfg below.
+    {
+        const bool p8_ok = bf16 && combo == 0 && batch == 1 && split == 1 && !a.colstats && !p->bnb_partials && !p->bn_finish && !a.stamps &&
+                           p->K % 64 == 0 && p->K >= 128 && p->lda % 8 == 0 && p->ldb % 8 == 0 && force_cfg < 0 &&
+                           (long long)p->M * p->lda * 2 < 0x7fffff00ll && (long long)p->N * p->ldb * 2 < 0x7fffff00ll && p8_epilogue_supported(a);
+        auto fits = [&](int c) {
+            const int bm = c == CFG_P8_128 ? 128 : 256, bn = c == CFG_P8_256 ? 256 : 128;
+            return p->M % bm == 0 && p->N % bn == 0 && !(c == CFG_P8_128 && p->rowsum_a);
+        };
+        int want = -1;
+        if (g_dbg_cfg >= CFG_P8_256 && g_dbg_cfg <= CFG_P8_128) want = g_dbg_cfg;
+        else if (g_dbg_cfg < 0 && p8_enabled()) want = p8_cfg(p);
+        if (p8_ok && want >= 0 && fits(want)) cfg = want;
+    }
     // (A deeper operand ring -- 5 / 8 slots for the long-K split weight gradients of the convolutions -- was built and
     // measured: 1.93 vs 1.92 ms per step on the 1x1 weight gradients, 0.70 vs 0.52 ms on the 3x3 ones, where the larger LDS
     // footprint costs a resident workgroup.  The kernel keeps the ring depth as a template parameter; 3 is what runs.)
     const int ring = cfg == CFG_128x128x32 ? HS_W3_RING : 3;
     int BM = 64, BN = 64;
-    if (cfg == CFG_128x128 || cfg == CFG_128x128x32) { BM = 128; BN = 128; }
+    if (cfg == CFG_P8_256) { BM = 256; BN = 256; }
+    else if (cfg == CFG_P8_256x128) { BM = 256; BN = 128; }
+    else if (cfg == CFG_P8_128) { BM = 128; BN = 128; }
+    else if (cfg == CFG_128x128 || cfg == CFG_128x128x32) { BM = 128; BN = 128; }
     else if (cfg == CFG_256x128 || cfg == CFG_256x128x32) { BM = 256; BN = 128; }
     else if (cfg == CFG_128x64 || cfg == CFG_STEM) { BM = 128; BN = 64; }
     a.tiles_m = ceil_div(p->M, BM);
@@ -338,7 +367,8 @@ static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q
         a.lds_stages = std::max(1, std::min(ring, kt));
         // L2 grouping: an XCD runs S workgroups at a time (32 CUs x resident workgroups); the panels they touch are
         // fewest when group_m * BM == (S / group_m) * BN
-        const int lds = bf16 ? a.lds_stages * (BM + BN) * kb_cfg * 2 : 2 * (BM + BN) * 32 * 4;
+        const bool p8 = cfg >= CFG_P8_256 && cfg <= CFG_P8_128;
+        const int lds = p8 ? 2 * (BM + BN) * 64 * 2 : bf16 ? a.lds_stages * (BM + BN) * kb_cfg * 2 : 2 * (BM + BN) * 32 * 4;
         const int per_cu = std::max(1, std::min(4, (160 * 1024) / lds));
         const double S = 32.0 * per_cu;
         int gm = (int)(sqrt(S * BN / BM) + 0.5);
@@ -476,7 +506,8 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     int st;
     ProfRec rec;
     const bool timed = prof_begin(stream, q.flops, (bf16 ? 0 : 2) + (conv ? 1 : 0), rec);
-    if (bf16) st = conv ? launch_bf16_conv(cfg, combo, a, grid, stream) : launch_bf16_plain(cfg, combo, a, grid, stream);
+    if (bf16 && cfg >= CFG_P8_256 && cfg <= CFG_P8_128) st = launch_bf16_p8(cfg, a, grid, stream);
+    else if (bf16) st = conv ? launch_bf16_conv(cfg, combo, a, grid, stream) : launch_bf16_plain(cfg, combo, a, grid, stream);
     else st = conv ? launch_f32_conv(cfg, combo, a, grid, stream) : launch_f32_plain(cfg, combo, vec, a, grid, stream);
     if (timed) {
         rec.M = p->M; rec.N = p->N; rec.K = p->K; rec.combo = combo; rec.cfg = cfg; rec.split = split; rec.batch = batch;

@@ -111,6 +111,7 @@ class DataParallel(nn.Module):
             zero_copy = not (getattr(module, "gate_enabled", False) or getattr(module, "global_local_enabled", False))
         self.zero_copy = bool(zero_copy)
         self._where = {}
+        self._hook_handles = []
         self._order = []                              # (bucket, index) in bucket order: the layout of the used bitmap
         for b in self.buckets:
             for i, p in enumerate(b.params):
@@ -118,7 +119,7 @@ class DataParallel(nn.Module):
                 self._order.append((b, i))
                 if self.zero_copy:
                     rt.grad_arena_register(p, b.views[i])
-                p.register_post_accumulate_grad_hook(self._on_grad)
+                self._hook_handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         # the text tower's gradients are produced on its own stream while the hooked AccumulateGrad nodes were created on
         # the ambient one; autograd orders the two correctly and says so on every backward
@@ -351,6 +352,17 @@ class DataParallel(nn.Module):
             b.events = {}
         self._covered = set()
         self._next = 0
+
+    def detach(self):
+        """undo the wrapping: remove the gradient hooks and the bucket slots (the module trains stand-alone again)"""
+        for h in self._hook_handles:
+            h.remove()
+        self._hook_handles = []
+        if self.zero_copy:
+            rt.grad_arena_clear()
+        for p in self._where:
+            p.grad = None
+        self._where = {}
 
     def zero_grad(self, set_to_none=True):
         self.module.zero_grad(set_to_none=set_to_none)

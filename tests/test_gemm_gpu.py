@@ -411,3 +411,114 @@ def test_forward_gemm_finishes_the_batchnorm_statistics(case):
         rv_ref = (1 - mom) * rv0.double() + mom * var_ref * M / (M - 1)
         assert ((rm.double() - rm_ref).abs() <= 1e-5 * (rm_ref.abs() + sd)).all()
         assert ((rv.double() - rv_ref).abs() <= 1e-4 * rv_ref.abs()).all()
+
+
+# ---- the phase-pipelined body (csrc/gemm_p8.h): 256x256 / 256x128 / 128x128 tiles, full tiles of nt GEMMs --------------------
+P8_CFGS = {7: (256, 256), 8: (256, 128), 9: (128, 128)}
+
+
+@pytest.mark.parametrize("cfg", [7, 8, 9])
+@pytest.mark.parametrize("K", [128, 192, 768])      # 2 K tiles (prologue + tail only), 3 (one steady iteration), 12 (BERT)
+def test_p8_body_is_exact_on_integer_data(cfg, K):
+    """Integer-valued bf16 operands: every product and partial sum is exact in f32, so ANY wrong fragment, slot, swizzle or
+    stale / early LDS read shows as a mismatch.  Asymmetric operands (guide: A = I checks with a symmetric B hide transposes).
+    Several output tiles per dimension so the XCD / L2-group tile map is exercised too."""
+    import ctypes as C
+    lib = L.lib()
+    lib.hs_gemm_debug.argtypes = [C.c_int32, C.c_int32]
+    bm, bn = P8_CFGS[cfg]
+    M, N = 3 * bm, 5 * bn
+    A, B = _rand((M, K), torch.bfloat16, True, 11), _rand((N, K), torch.bfloat16, True, 12)
+    ref = A.double() @ B.double().t()
+    bias = torch.arange(N, dtype=torch.float32) - 7.0
+    try:
+        lib.hs_gemm_debug(cfg, 0)
+        for rep in range(3):       # a race would not show every time: the same launch three times
+            D = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+            raw.gemm(A.to(DEV), B.to(DEV), D, M, N, K, lda=K, ldb=K)
+            assert torch.equal(D.cpu().double(), ref), f"cfg {cfg} K {K} rep {rep}: f32 result"
+        Db = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        raw.gemm(A.to(DEV), B.to(DEV), Db, M, N, K, lda=K, ldb=K, bias=bias.to(DEV))
+        want = (ref + bias.double()).to(torch.bfloat16)
+        assert torch.equal(Db.cpu(), want), f"cfg {cfg} K {K}: bf16 result + bias"
+    finally:
+        lib.hs_gemm_debug(-1, 0)
+
+
+def test_p8_body_epilogues_match_the_generic_body():
+    """every epilogue feature set the pipelined body has code for, against the generic body on the same operands (random
+    data: both accumulate in f32 in K order inside a tile, so the results agree to the last bit except where the K walk is
+    split differently -- it is not: both walk K in one pass)"""
+    import ctypes as C
+    lib = L.lib()
+    lib.hs_gemm_debug.argtypes = [C.c_int32, C.c_int32]
+    M, N, K = 512, 768, 320
+    bf = torch.bfloat16
+    A, B = _rand((M, K), bf, False, 21).to(DEV), _rand((N, K), bf, False, 22).to(DEV)
+    bias = _rand((N,), torch.float32, False, 23).to(DEV)
+    res = _rand((M, N), bf, False, 24).to(DEV)
+    u = _rand((M, N), bf, False, 25).to(DEV)
+
+    def run(cfg, **kw):
+        lib.hs_gemm_debug(cfg, 0)
+        try:
+            outs = {}
+            D = torch.full((M, N), float("nan"), dtype=kw.pop("out", bf), device=DEV)
+            pre = torch.full((M, N), float("nan"), dtype=bf, device=DEV) if kw.pop("want_pre", False) else None
+            raw.gemm(A, B, D, M, N, K, lda=K, ldb=K, preact=pre, **kw)
+            outs["D"] = D.float().cpu()
+            if pre is not None:
+                outs["pre"] = pre.float().cpu()
+            return outs
+        finally:
+            lib.hs_gemm_debug(-1, 0)
+    cases = {
+        "plain": {},
+        "bias": dict(bias=bias),
+        "bias+gelu+preact": dict(bias=bias, act=L.ACT_GELU, want_pre=True),
+        "bias+residual": dict(bias=bias, residual=res),
+        "bias+dropout+residual": dict(bias=bias, residual=res, dropout_p=0.1, dropout_seed=1234),
+        "gelu-grad multiplier": dict(mul_mode=L.MUL_GELU_GRAD, mul_src=u),
+        "residual": dict(residual=res),
+        "f32 out": dict(out=torch.float32),
+    }
+    for name, kw in cases.items():
+        want = run(2, **dict(kw))        # 64x64 tiles of the generic body
+        for cfg in (7, 8, 9):
+            if cfg == 7 and M % 256 == 0 and N % 256 == 0 or cfg == 8 and N % 128 == 0 or cfg == 9:
+                got = run(cfg, **dict(kw))
+                for k in want:
+                    assert torch.equal(got[k], want[k]), f"{name}: cfg {cfg} {k} differs from the generic body"
+
+
+def test_p8_body_row_sums_and_segments():
+    """the K-contiguous weight gradient of a BertLayer on the pipelined body: dW = dY^T X with the bias gradient as row sums,
+    Q/K/V in one launch as three output segments (reference: transformers BertSelfAttention's three Linear layers)"""
+    import ctypes as C
+    lib = L.lib()
+    lib.hs_gemm_debug.argtypes = [C.c_int32, C.c_int32]
+    rows, out_f, in_f = 640, 768, 512
+    dYt = _rand((out_f, rows), torch.bfloat16, True, 31)
+    Xt = _rand((in_f, rows), torch.bfloat16, True, 32)
+    for cfg in (7, 8):
+        try:
+            lib.hs_gemm_debug(cfg, 0)
+            dW = torch.full((out_f, in_f), float("nan"), dtype=torch.float32, device=DEV)
+            db = torch.full((out_f,), float("nan"), dtype=torch.float32, device=DEV)
+            raw.gemm(dYt.to(DEV), Xt.to(DEV), dW, out_f, in_f, rows, lda=rows, ldb=rows, rowsum_a=db)
+            assert torch.equal(dW.cpu().double(), dYt.double() @ Xt.double().t()), cfg
+            assert torch.equal(db.cpu().double(), dYt.double().sum(1)), cfg
+        finally:
+            lib.hs_gemm_debug(-1, 0)
+
+
+def test_p8_body_is_what_bert_sized_projections_run():
+    """the launcher's own choice (no override) on the fused Q/K/V projection of BERT-base at 4096 tokens takes the pipelined
+    body (HAMSPINE_P8 default on) and agrees with float64"""
+    M, N, K = 4096, 2304, 768
+    A, B = _rand((M, K), torch.bfloat16, False, 41), _rand((N, K), torch.bfloat16, False, 42)
+    bias = _rand((N,), torch.float32, False, 43)
+    D = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    raw.gemm(A.to(DEV), B.to(DEV), D, M, N, K, lda=K, ldb=K, bias=bias.to(DEV))
+    ref = A.double() @ B.double().t() + bias.double()
+    assert (D.cpu().double() - ref).abs().max() <= 2.0 ** -7 * ref.abs().max()
