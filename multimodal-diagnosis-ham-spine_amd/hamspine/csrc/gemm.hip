@@ -221,6 +221,7 @@ static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q
     a.res_pre_act = p->residual_before_act;
     a.stamps = g_dbg_stamps;
     a.epi_generic = (g_dbg_ablate & 32) ? 1 : 0;
+    a.dbg = g_dbg_ablate;
     a.rowsum[0] = p->rowsum_a;
     a.rowsum[1] = p->rowsum_seg[0];
     a.rowsum[2] = p->rowsum_seg[1];
@@ -333,7 +334,7 @@ static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q
     // The phase-pipelined body (gemm_p8.h): plain nt GEMMs whose tiles are all full, no split / batch / statistics riders, and
     // an epilogue feature set it has code for.  Which of its tiles (if any) a shape takes: p8_cfg below.
     {
-        const bool p8_ok = bf16 && combo == 0 && batch == 1 && split == 1 && !a.colstats && !p->bnb_partials && !p->bn_finish && !a.stamps &&
+        const bool p8_ok = bf16 && combo == 0 && batch == 1 && split == 1 && !a.colstats && !p->bnb_partials && !p->bn_finish &&
                            p->K % 64 == 0 && p->K >= 128 && p->lda % 8 == 0 && p->ldb % 8 == 0 && force_cfg < 0 &&
                            (long long)p->M * p->lda * 2 < 0x7fffff00ll && (long long)p->N * p->ldb * 2 < 0x7fffff00ll && p8_epilogue_supported(a);
         auto fits = [&](int c) {

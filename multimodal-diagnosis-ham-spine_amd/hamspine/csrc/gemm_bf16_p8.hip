@@ -2,6 +2,9 @@
 #include "gemm_launch.h"
 #include "gemm_p8.h"
 namespace hs {
+__global__ __launch_bounds__(512) void gemm_bf16_p8_256_diag_kernel(const GemmArgs a) {
+    gemm_bf16_p8_body<256, 256, 2, 4, false, true, true>(a, blockIdx.x);
+}
 template <typename K>
 static int launch_p8(K kernel, int lds, int threads, const GemmArgs& a, dim3 grid, hipStream_t s) {
     if (lds_attr_needed((const void*)kernel)) HS_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -13,6 +16,7 @@ int launch_bf16_p8(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
     const bool rs = a.rowsum[0] != nullptr;
     switch (cfg) {
         case CFG_P8_256:
+            if (a.stamps && !rs) return launch_p8(gemm_bf16_p8_256_diag_kernel, 128 * 1024, 512, a, grid, s);
             return rs ? launch_p8(gemm_bf16_p8_256_kernel<true>, 128 * 1024, 512, a, grid, s)
                       : launch_p8(gemm_bf16_p8_256_kernel<false>, 128 * 1024, 512, a, grid, s);
         case CFG_P8_256x128:

@@ -82,6 +82,7 @@ struct GemmArgs {
     float* rowsum[3];          // optional (row-contiguous A): rowsum[seg][m] = sum_k A[k][m], the bias gradient of a wgrad GEMM
     int vec16;                    // bf16 result rows allow 16-byte (8-column) stores: N, ldd, batch strides % 8 == 0, bases 16-byte aligned
     int epi_generic;              // measurement only (hs_gemm_debug bit 32): always take the generic epilogue body
+    int dbg;                      // measurement only: the hs_gemm_debug ablation bits
     unsigned long long* stamps;   // measurement only (hs_gemm_debug_stamps): 6 shader-clock stamps per workgroup, else NULL
 };
 // stamp k of this workgroup: 0 start (clock taken at entry, stored together with stamp 1), 1 first DMA issued, 2 first tile landed (barrier passed), 3 K loop done,

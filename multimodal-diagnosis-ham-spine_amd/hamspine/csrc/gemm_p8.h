@@ -35,7 +35,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // BM x BN tile, WGM x WGN waves.  RS: also the row sums of A (bias gradient of a K-contiguous weight gradient, see gemm_core.h).
 // STAG: waves NW/2.. run one barrier behind (two waves per SIMD); off for 4-wave workgroups (one wave per SIMD, the CU's
 // second workgroup is the partner).
-template <int BM, int BN, int WGM, int WGN, bool RS, bool STAG>
+// DIAG (measurement build of the kernel, launched only when hs_gemm_debug_stamps armed a buffer): waves 0 and NW/2 stamp the
+// shader clock around every segment of ONE K tile in the middle of the walk: 17 stamps per wave at a.stamps[(bx * 2 + group) * 20].
+template <int BM, int BN, int WGM, int WGN, bool RS, bool STAG, bool DIAG = false>
 __device__ __forceinline__ void gemm_bf16_p8_body(const GemmArgs& a, const int bx) {
     typedef bf16_t T;
     constexpr int BK = 64, NW = WGM * WGN;
@@ -59,6 +61,9 @@ __device__ __forceinline__ void gemm_bf16_p8_body(const GemmArgs& a, const int b
     tile_from_block(a, tm, tn, bx);
     const int m0 = tm * BM, n0 = tn * BN;
     const int ntiles = a.K / BK;
+    // (A rotated K walk -- each tile starting at a different K tile so that the workgroups sharing an operand panel through
+    // one XCD's L2 do not miss on the same lines at the same moment -- was built and measured: 2.0 instead of 1.39 us per K
+    // tile at 4096 x 4096.  Walking in lockstep is what lets the L2 merge the sharers' misses into one fetch.)
 
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.A, (unsigned)min(a.a_bytes, 0x7fffff00ull));
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.B, (unsigned)min(a.b_bytes, 0x7fffff00ull));
@@ -197,34 +202,68 @@ __device__ __forceinline__ void gemm_bf16_p8_body(const GemmArgs& a, const int b
         }
     }
 
+    unsigned long long stamp[DIAG ? 17 : 1];
+    int nst = 0;
+    auto STAMP = [&](int t) {
+        if constexpr (DIAG) {
+            if (t == ntiles / 2 && nst < 17) {
+                __builtin_amdgcn_sched_barrier(0);
+                stamp[nst++] = __builtin_readcyclecounter();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         // DMAs that the steady-state counts assume behind the awaited ones do not exist near the end of the K walk: drain instead
         const bool tail = t + 2 >= ntiles;
         // phase 0: quadrant (0, 0)
+        STAMP(t);
         read_a(buf, 0);
         read_b(buf, I0{});
         dma_a(t + 1, 1);                       // slot Aq1 of the other buffer: read in phase 2 of tile t - 1
+        if constexpr (DIAG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); STAMP(t); }
         fence_r(W_P1{}, tail);
+        STAMP(t);
         mma(I0{}, I0{}, true);
+        STAMP(t);
         fence_m();
         // phase 1: quadrant (0, 1)
+        STAMP(t);
         read_b(buf, I1{});
         dma_a(t + 2, 0);                       // slot Aq0 of this buffer: read in phase 0
+        if constexpr (DIAG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); STAMP(t); }
         fence_r(W_P2{}, tail);
+        STAMP(t);
         mma(I0{}, I1{}, false);
+        STAMP(t);
         fence_m();
         // phase 2: quadrant (1, 1)
+        STAMP(t);
         read_a(buf, 1);
         dma_b(t + 2, 0);                       // slot Bq0 of this buffer: read in phase 0
+        if constexpr (DIAG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); STAMP(t); }
         fence_r(W_NONE{}, false);
+        STAMP(t);
         mma(I1{}, I1{}, true);
+        STAMP(t);
         fence_m();
         // phase 3: quadrant (1, 0), all operands in registers
+        STAMP(t);
         dma_b(t + 2, 1);                       // slot Bq1 of this buffer: read in phase 1
         fence_r(W_P0{}, tail);
+        STAMP(t);
         mma(I1{}, I0{}, false);
+        STAMP(t);
         fence_m();
+    }
+    if constexpr (DIAG) {
+        if (a.stamps && lane == 0 && (wave == 0 || wave == NW / 2)) {
+            unsigned long long* o = a.stamps + ((long long)bx * 2 + (wave ? 1 : 0)) * 20;
+#pragma unroll
+            for (int i = 0; i < 17; ++i) o[i] = stamp[i];
+            o[17] = (unsigned long long)nst;
+        }
     }
     if constexpr (STAG) {
         if (wave < NW / 2) __builtin_amdgcn_s_barrier();      // the barrier the late group still owes
@@ -303,6 +342,7 @@ template <bool RS>
 __global__ __launch_bounds__(512) void gemm_bf16_p8_256_kernel(const GemmArgs a) {
     gemm_bf16_p8_body<256, 256, 2, 4, RS, true>(a, blockIdx.x);
 }
+__global__ __launch_bounds__(512) void gemm_bf16_p8_256_diag_kernel(const GemmArgs a);   // measurement build (gemm_bf16_p8.hip)
 // 256 x 128 tile, 8 waves (4 x 2, 64 x 64 per wave), 96 KiB: the shapes whose N gives too few 256-wide tiles
 template <bool RS>
 __global__ __launch_bounds__(512) void gemm_bf16_p8_256x128_kernel(const GemmArgs a) {

@@ -447,8 +447,7 @@ def test_p8_body_is_exact_on_integer_data(cfg, K):
 
 def test_p8_body_epilogues_match_the_generic_body():
     """every epilogue feature set the pipelined body has code for, against the generic body on the same operands (random
-    data: both accumulate in f32 in K order inside a tile, so the results agree to the last bit except where the K walk is
-    split differently -- it is not: both walk K in one pass)"""
+    data: both accumulate in f32 and walk K in the same order, so the results agree to the last bit)"""
     import ctypes as C
     lib = L.lib()
     lib.hs_gemm_debug.argtypes = [C.c_int32, C.c_int32]
