@@ -5,6 +5,7 @@ Workloads (`--workload`, default c2 = the configuration BA
   c2  ResNet50 + BERT-base (L=128) + cross-attention FusionModule + MLP head, batch 32 per GPU        (configs[1])
   c3  MIBF-Net: ResNet50 + fc768, BERT-base CLS, IBFA both ways, three heads, MP-Loss, batch 32 per GPU (configs[2])
   c4  ConNeXT: ConvNeXt-base + BERT-base CLS + conv cross-attention, batch 64 per GPU                  (configs[3])
+  c5  ResNet18 multi-scale taps x BERT through 3 CrossAttentionBlocks + global-local + gate + KAN head  (configs[4])
 224x224 synthetic images, 128-token synthetic captions, bf16 activations with f32 accumulation, random-init weights of
 the real architecture, train-mode BatchNorm and dropout, weak scaling (per-GPU batch fixed, as reference
 mibf_net/train_resnet.py:111-119).
@@ -58,7 +59,12 @@ WORKLOADS = {
                          "GPU, fused Adam, train-mode BatchNorm and dropout"),
     "c4": (64, 7, 10.27, "C4: ConNeXT (ConvNeXt-base + BERT-base CLS + conv cross-attention), 224x224, L=128, batch 64 per GPU, "
                          "CE, fused Adam, train-mode dropout / stochastic depth"),
+    "c5": (32, 7, 2.922, "C5: hierarchical fusion -- ResNet18 layer2/3/4 taps x 3 CrossAttentionBlocks (MultiScaleFusionModule) + "
+                         "global-local dual stream (two image-tower passes: full image and 0.6 centre crop) + BERT-base(L=128) + "
+                         "dual-expert gate + KAN head, 224x224, batch 32 per GPU, CE(label_smoothing=0.02), fused AdamW"),
 }
+C5_KW = dict(fusion_type="multiscale", classifier_type="kan", kan_num_groups=8, kan_act_mode="gelu", gate_enabled=True,
+             global_local_enabled=True, global_local_crop_ratio=0.6)      # reference model.py:22-58; configs[4] of BASELINE.json
 
 
 def log(msg):
@@ -96,6 +102,10 @@ def build_workload(name, device, rank):
             net = product_model.MultimodalBaselineModel(
                 num_classes=classes, hidden_dim=256, dropout=0.2, pretrained_image=False, image_weights_path=None,
                 text_model_name=bdir, num_heads=8, image_backbone="resnet50", classifier_type="mlp", fusion_type="basic")
+        elif name == "c5":
+            net = product_model.MultimodalBaselineModel(
+                num_classes=classes, hidden_dim=256, dropout=0.2, pretrained_image=False, image_weights_path=None,
+                text_model_name=bdir, num_heads=8, image_backbone="resnet18", **C5_KW)
         elif name == "c3":
             from mibf_net.model_resnet import Resnet50WithOurs
             net = Resnet50WithOurs(num_labels=classes, loss_class="KL_loss", bert_path=bdir)
@@ -104,8 +114,8 @@ def build_workload(name, device, rank):
             net = OurClassfierConvnextV2(num_labels=classes, pretrained=False, bert_path=bdir)
     net = net.to(device).train()
     images, ids, mask, labels = synthetic(rank, device, batch, classes)
-    if name == "c2":
-        def fwd_loss():
+    if name in ("c2", "c5"):
+        def fwd_loss():                                                                  # scripts/train.py:373-381
             logits = net.classifier(net.forward_features(images, ids, mask))
             return F.cross_entropy(logits, labels, label_smoothing=0.02)
         make_opt = lambda: FusedAdamW(net.parameters(), lr=1e-4, weight_decay=0.01)      # scripts/train.py:257-261
@@ -403,9 +413,10 @@ def cpu_leg(workload, steps=3):
                     hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
     torch.manual_seed(0)
     images, ids, mask, labels = synthetic_batch(batch, HW, SEQ, VOCAB, classes, seed=1234, min_len=16)
-    if workload == "c2":
-        net = om.OMultimodalBaselineModel(num_classes=classes, bert_cfg=bert_cfg, hidden_dim=256, dropout=0.2, num_heads=8,
-                                          image_backbone="resnet50", classifier_type="mlp", fusion_type="basic").train()
+    if workload in ("c2", "c5"):
+        kw = dict(image_backbone="resnet50", classifier_type="mlp", fusion_type="basic") if workload == "c2" else \
+            dict(image_backbone="resnet18", **C5_KW)
+        net = om.OMultimodalBaselineModel(num_classes=classes, bert_cfg=bert_cfg, hidden_dim=256, dropout=0.2, num_heads=8, **kw).train()
         opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=0.01)
 
         def fwd_loss():
@@ -483,7 +494,8 @@ def main():
         ms_step = dt / args.steps * 1e3
         metric = {"c2": "training images/sec, ResNet50+BERT-base 224px bs32",
                   "c3": "training images/sec, MIBF-Net (ResNet50+BERT-base, IBFA, MP-Loss) 224px bs32",
-                  "c4": "training images/sec, ConNeXT (ConvNeXt-base+BERT-base) 224px bs64"}[args.workload]
+                  "c4": "training images/sec, ConNeXT (ConvNeXt-base+BERT-base) 224px bs64",
+                  "c5": "training images/sec, hierarchical fusion (ResNet18 multi-scale + global-local + gate + KAN head) 224px bs32"}[args.workload]
         out = {
             "metric": metric,
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -472,8 +472,10 @@ hs_status hs_kan_unpack_wgrad(const float* dwcat, const float* spline_w, const f
                               float* d_scaler, int32_t out_f, int32_t in_f, int32_t nb, void* stream);
 /* noisy top-k gating on clean = x@w_gate (and raw_noise = x@w_noise when noisy): gates (B,E), load-balancing loss
    coef*(cv^2(importance)+cv^2(load)), plus everything the backward needs (p, top: (B,17) int32, z, sigma,
-   loadrow, d_imp[E], d_load[E]).  E <= 16. */
-hs_status hs_moe_gate_fwd(const float* clean, const float* raw_noise, int32_t B, int32_t E, int32_t k, int32_t noisy,
+   loadrow, d_imp[E], d_load[E]).  E <= 16.
+   noise: optional (B,E) standard-normal draw to use instead of the counter RNG (NULL = draw from `seed`): the reference's
+   torch.randn_like(clean_logits), moe.py:247, recorded by a caller that wants its gating reproduced exactly. */
+hs_status hs_moe_gate_fwd(const float* clean, const float* raw_noise, const float* noise, int32_t B, int32_t E, int32_t k, int32_t noisy,
                           float noise_eps, uint64_t seed, float coef, float* gates, float* p, int32_t* top, float* z,
                           float* sigma, float* loadrow, float* loss, float* d_imp, float* d_load, void* stream);
 hs_status hs_moe_gate_bwd(const float* clean, const float* raw_noise, const float* p, const int32_t* top, const float* z,
@@ -485,6 +487,18 @@ hs_status hs_moe_combine_fwd(const float* gates, const float* const* outs, float
                              void* stream);
 hs_status hs_moe_combine_bwd(const float* gates, const float* const* outs, const float* dy, float* const* douts,
                              float* dgates, int32_t B, int32_t E, int32_t O, void* stream);
+
+/* Sparse dispatch (SparseDispatcher, moe.py:48-112: expert e sees only the rows with gates[b][e] > 0, i.e. k/E of the work).
+   hs_moe_dispatch_index: idx[e*B + 0 .. count[e]) = those rows, ascending.  hs_rows_gather: dst[i] = src[idx[i]] (rows of D
+   floats).  hs_rows_scatter_add: dst[idx[i]] += scale[idx[i]*ld_scale + col] * src[i] (scale may be NULL; idx unique, so the
+   update is a plain read-modify-write and deterministic).  hs_rows_scatter_add_bwd: the backward of the weighted scatter for
+   one expert column: dsrc[i] = gates[idx[i]][col] * dy[idx[i]], dgates[idx[i]][col] = <dy[idx[i]], src[i]>. */
+hs_status hs_moe_dispatch_index(const float* gates, int32_t B, int32_t E, int32_t* idx, int32_t* count, void* stream);
+hs_status hs_rows_gather(const float* src, const int32_t* idx, float* dst, int32_t n, int32_t D, void* stream);
+hs_status hs_rows_scatter_add(float* dst, const int32_t* idx, const float* scale, int32_t ld_scale, int32_t col, const float* src,
+                              int32_t n, int32_t D, void* stream);
+hs_status hs_rows_scatter_add_bwd(const float* dy, const int32_t* idx, const float* gates, int32_t E, int32_t col, const float* src,
+                                  float* dsrc, float* dgates, int32_t n, int32_t D, void* stream);
 
 /* ------------------------------------------------------------------------------------------- */
 /* Composite executors: one call = one nn.Module forward (or backward) of the reference's module  */

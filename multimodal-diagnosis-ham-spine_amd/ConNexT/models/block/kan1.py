@@ -122,7 +122,12 @@ class KAN1(torch.nn.Module):
 
     def forward(self, x, update_grid=False):
         if x.numel() == 0:
-            return torch.zeros((*x.shape[:-1], self.output_dim), device=x.device)
+            # an expert that received no rows (reference: the empty batch flows through every op and its parameters get
+            # zero gradients, not None): an empty output that still hangs on the parameters
+            y = torch.zeros((*x.shape[:-1], self.output_dim), device=x.device)
+            if torch.is_grad_enabled():
+                y = y + sum((p.reshape(-1)[:1].sum() * 0.0 for p in self.parameters() if p.requires_grad), torch.zeros((), device=x.device))
+            return y
         for layer in self.layers:
             if update_grid:
                 layer.update_grid(x)

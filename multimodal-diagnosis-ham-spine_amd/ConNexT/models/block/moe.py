@@ -1,9 +1,12 @@
 """Sparsely-gated mixture of KAN experts (reference ConNexT/models/block/moe.py:171-291) on the hamspine kernels.
 
-Gating (noisy top-k, load / importance cv^2 loss) is one fused node; experts are evaluated densely and combined with
-their gate columns -- rows whose gate is zero contribute exactly nothing, so outputs and gradients equal the reference's
-gather/scatter dispatch (KAN experts have no cross-sample coupling) without the host sync of `.tolist()`.
-Training-mode noise comes from hamspine's counter RNG (cannot equal torch.randn_like bit-for-bit)."""
+Gating (noisy top-k, load / importance cv^2 loss) is one fused node (hs_moe_gate_fwd / _bwd).  Dispatch is SPARSE as in the
+reference (moe.py:48-112): expert e receives only the rows whose gate is > 0 (hs_moe_dispatch_index builds the per-expert
+row lists on the device, hs_rows_gather collects them), runs its KAN stack on that k/E share of the batch, and
+hs_rows_scatter_add stitches the gate-weighted outputs back.  Like the reference, the dispatcher reads the experts' batch
+sizes back to the host (`.tolist()`, moe.py:60).  Training-mode noise comes from hamspine's counter RNG (it cannot equal
+torch.randn_like bit for bit); a caller that needs the reference's draw reproduced sets `moe.gating_noise` to the recorded
+(batch, experts) standard-normal tensor before the call (consumed once)."""
 import torch
 import torch.nn as nn
 
@@ -13,23 +16,24 @@ from .kan1 import KAN1
 
 
 class SparseDispatcher(object):
-    """API of moe.py:17-112 on top of the dense gate matrix: dispatch() hands every expert the full batch, combine() weights
-    by the gates (zero for rows the reference would not have dispatched)."""
+    """moe.py:17-112: `dispatch` -> one input tensor per expert (the rows with gates[b, e] > 0, ascending b), `combine` ->
+    the gate-weighted sum back in batch order, `expert_to_gates` -> the nonzero gate values per expert."""
 
     def __init__(self, num_experts, gates):
         self._gates = gates
         self._num_experts = num_experts
+        self._idx, self._part_sizes = K.moe_dispatch_index(gates)
 
     def dispatch(self, inp):
-        return [inp for _ in range(self._num_experts)]
+        return [K.RowsGatherFn.apply(inp, self._idx[e], n) for e, n in enumerate(self._part_sizes)]
 
     def combine(self, expert_out, multiply_by_gates=True):
         if not multiply_by_gates:
             raise NotImplementedError("combine(multiply_by_gates=False) is not implemented")
-        return K.MoECombineFn.apply(self._gates, *expert_out)
+        return K.MoESparseCombineFn.apply(self._gates, self._idx, self._part_sizes, self._gates.shape[0], *expert_out)
 
     def expert_to_gates(self):
-        return [self._gates[:, e] for e in range(self._num_experts)]
+        return [self._gates[self._idx[e, :n].long(), e] for e, n in enumerate(self._part_sizes)]
 
 
 class MoE(nn.Module):
@@ -48,13 +52,15 @@ class MoE(nn.Module):
         self.softmax = nn.Softmax(1)
         self.register_buffer("mean", torch.tensor([0.0]))
         self.register_buffer("std", torch.tensor([1.0]))
+        self.gating_noise = None
         assert self.k <= self.num_experts
 
     def forward(self, x, loss_coef=1e-2):
         if x.dtype != torch.float32:
             x = x.float()
         noisy = bool(self.noisy_gating and self.training)
-        gates, loss = K.MoEGateFn.apply(x, self.w_gate, self.w_noise, self.k, noisy, float(loss_coef))
+        noise, self.gating_noise = self.gating_noise, None
+        gates, loss = K.MoEGateFn.apply(x, self.w_gate, self.w_noise, self.k, noisy, float(loss_coef), noise if noisy else None)
         dispatcher = SparseDispatcher(self.num_experts, gates)
         expert_inputs = dispatcher.dispatch(x)
         outs = [self.experts[i](expert_inputs[i]) for i in range(self.num_experts)]

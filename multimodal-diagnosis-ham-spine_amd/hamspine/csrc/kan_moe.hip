@@ -148,7 +148,8 @@ __device__ __forceinline__ float gauss(unsigned long long seed, unsigned long lo
 }
 
 // outputs per row: gates[E], p[E] (softmax), top[k+1] indices, z[E] noise, sigma[E], loadrow[E]
-__global__ void moe_gate_fwd_kernel(const float* __restrict__ clean, const float* __restrict__ raw_noise, int B, int E, int k,
+__global__ void moe_gate_fwd_kernel(const float* __restrict__ clean, const float* __restrict__ raw_noise,
+                                    const float* __restrict__ noise, int B, int E, int k,
                                     int noisy, float noise_eps, unsigned long long seed, float* __restrict__ gates,
                                     float* __restrict__ p_out, int* __restrict__ top_out, float* __restrict__ z_out,
                                     float* __restrict__ sigma_out, float* __restrict__ loadrow) {
@@ -160,7 +161,9 @@ __global__ void moe_gate_fwd_kernel(const float* __restrict__ clean, const float
         if (noisy) {
             const float r = raw_noise[(long long)b * E + e];
             sg[e] = (r > 20.f ? r : log1pf(__expf(r))) + noise_eps;   // softplus (torch threshold 20)
-            z[e] = gauss(seed, (unsigned long long)b * E + e);
+            // the standard-normal draw: the caller's tensor when it supplies one (a recorded torch.randn_like draw: the
+            // reference's noise, moe.py:247), else the counter RNG
+            z[e] = noise ? noise[(long long)b * E + e] : gauss(seed, (unsigned long long)b * E + e);
             h[e] = c[e] + z[e] * sg[e];
         } else {
             sg[e] = 0.f;
@@ -343,6 +346,58 @@ __global__ void moe_combine_bwd_kernel(const float* __restrict__ gates, const Ex
     if (lane == 0) dgates[be] = acc;
 }
 
+// ---- sparse dispatch (SparseDispatcher, moe.py:48-112): expert e works on the rows whose gate is > 0 only ------------------
+// idx[e][0 .. count[e]) = rows b (ascending) with gates[b][e] > 0.  One wave per expert walks the rows 64 at a time.
+__global__ void moe_dispatch_index_kernel(const float* __restrict__ gates, int B, int E, int* __restrict__ idx, int* __restrict__ count) {
+    const int e = blockIdx.x, lane = threadIdx.x;
+    int n = 0;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int b = b0 + lane;
+        const bool on = b < B && gates[(long long)b * E + e] > 0.f;
+        const unsigned long long m = __ballot(on);
+        if (on) idx[(long long)e * B + n + __popcll(m & ((1ull << lane) - 1ull))] = b;
+        n += __popcll(m);
+    }
+    if (lane == 0) count[e] = n;
+}
+// dst[i][:] = src[idx[i]][:]
+__global__ void rows_gather_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, int n, int D) {
+    const long long total = (long long)n * D;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / D;
+        dst[i] = src[(long long)idx[r] * D + (i - r * D)];
+    }
+}
+// dst[idx[i]][:] += scale[idx[i] * ld_scale + col] * src[i][:]   (idx unique: plain read-modify-write, deterministic)
+__global__ void rows_scatter_add_kernel(float* __restrict__ dst, const int* __restrict__ idx, const float* __restrict__ scale,
+                                        int ld_scale, int col, const float* __restrict__ src, int n, int D) {
+    const long long total = (long long)n * D;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / D;
+        const int b = idx[r];
+        const float sc = scale ? scale[(long long)b * ld_scale + col] : 1.f;
+        dst[(long long)b * D + (i - r * D)] += sc * src[i];
+    }
+}
+// backward of the weighted scatter: d src[i][:] = g * dy[idx[i]][:],  dgates[idx[i]][col] = dy[idx[i]][:] . src[i][:]   (one wave per row)
+__global__ void rows_scatter_add_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx, const float* __restrict__ gates,
+                                            int E, int col, const float* __restrict__ src, float* __restrict__ dsrc,
+                                            float* __restrict__ dgates, int n, int D) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int b = idx[r];
+    const float g = gates[(long long)b * E + col];
+    float acc = 0.f;
+    for (int o = lane; o < D; o += 64) {
+        const float d = dy[(long long)b * D + o];
+        acc += d * src[(long long)r * D + o];
+        dsrc[(long long)r * D + o] = g * d;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) dgates[(long long)b * E + col] = acc;
+}
+
 // ============================================================================================
 // SupCon loss (scripts/train.py:23-44), single block, B <= 256, D <= 1024; loss + d(loss)/d(features)
 // ============================================================================================
@@ -500,14 +555,14 @@ hs_status hs_kan_unpack_wgrad(const float* dwcat, const float* spline_w, const f
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
-hs_status hs_moe_gate_fwd(const float* clean, const float* raw_noise, int32_t B, int32_t E, int32_t k, int32_t noisy,
+hs_status hs_moe_gate_fwd(const float* clean, const float* raw_noise, const float* noise, int32_t B, int32_t E, int32_t k, int32_t noisy,
                           float noise_eps, uint64_t seed, float coef, float* gates, float* p, int32_t* top, float* z,
                           float* sigma, float* loadrow, float* loss, float* d_imp, float* d_load, void* stream) {
     HS_REQUIRE(clean && gates && p && top && z && sigma && loadrow && loss && d_imp && d_load, "moe_gate_fwd: null argument");
     HS_REQUIRE(E >= 1 && E <= MOE_MAXE && k >= 1 && k <= E, "moe_gate_fwd: need 1 <= k <= E <= %d", MOE_MAXE);
     HS_REQUIRE(!noisy || raw_noise, "moe_gate_fwd: noisy gating needs raw_noise");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(moe_gate_fwd_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, s, clean, raw_noise, B, E, k, noisy,
+    hipLaunchKernelGGL(moe_gate_fwd_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, s, clean, raw_noise, noise, B, E, k, noisy,
                        noise_eps, (unsigned long long)seed, gates, p, (int*)top, z, sigma, loadrow);
     HS_LAUNCH_CHECK();
     hipLaunchKernelGGL(moe_aux_kernel, dim3(1), dim3(64), 0, s, gates, loadrow, B, E, coef, loss, d_imp, d_load);
@@ -548,6 +603,37 @@ hs_status hs_moe_combine_bwd(const float* gates, const float* const* outs, const
     }
     hipLaunchKernelGGL(moe_combine_bwd_kernel, dim3(ceil_div(B * E, 4)), dim3(256), 0, (hipStream_t)stream, gates, ep, dy, dp,
                        dgates, B, E, O);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_moe_dispatch_index(const float* gates, int32_t B, int32_t E, int32_t* idx, int32_t* count, void* stream) {
+    HS_REQUIRE(gates && idx && count && B >= 1 && E >= 1 && E <= MOE_MAXE, "moe_dispatch_index: bad argument");
+    hipLaunchKernelGGL(moe_dispatch_index_kernel, dim3(E), dim3(64), 0, (hipStream_t)stream, gates, B, E, (int*)idx, (int*)count);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_rows_gather(const float* src, const int32_t* idx, float* dst, int32_t n, int32_t D, void* stream) {
+    if (n == 0) return HS_OK;                       // an expert without rows: nothing to move (the tensors may be empty)
+    HS_REQUIRE(src && idx && dst && n > 0 && D >= 1, "rows_gather: bad argument");
+    hipLaunchKernelGGL(rows_gather_kernel, dim3(grid_for((long long)n * D)), dim3(256), 0, (hipStream_t)stream, src, (const int*)idx, dst, n, D);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_rows_scatter_add(float* dst, const int32_t* idx, const float* scale, int32_t ld_scale, int32_t col, const float* src,
+                              int32_t n, int32_t D, void* stream) {
+    if (n == 0) return HS_OK;
+    HS_REQUIRE(dst && idx && src && n > 0 && D >= 1, "rows_scatter_add: bad argument");
+    hipLaunchKernelGGL(rows_scatter_add_kernel, dim3(grid_for((long long)n * D)), dim3(256), 0, (hipStream_t)stream, dst, (const int*)idx,
+                       scale, ld_scale, col, src, n, D);
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
+hs_status hs_rows_scatter_add_bwd(const float* dy, const int32_t* idx, const float* gates, int32_t E, int32_t col, const float* src,
+                                  float* dsrc, float* dgates, int32_t n, int32_t D, void* stream) {
+    if (n == 0) return HS_OK;
+    HS_REQUIRE(dy && idx && gates && src && dsrc && dgates && n > 0 && D >= 1, "rows_scatter_add_bwd: bad argument");
+    hipLaunchKernelGGL(rows_scatter_add_bwd_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, (hipStream_t)stream, dy, (const int*)idx, gates, E,
+                       col, src, dsrc, dgates, n, D);
     HS_LAUNCH_CHECK();
     return HS_OK;
 }

@@ -23,7 +23,11 @@ def _l():
         l.hs_kan_features_bwd.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
         l.hs_kan_pack_weight.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
         l.hs_kan_unpack_wgrad.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
-        l.hs_moe_gate_fwd.argtypes = [vp, vp, i32, i32, i32, i32, f32, u64, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        l.hs_moe_gate_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, u64, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        l.hs_moe_dispatch_index.argtypes = [vp, i32, i32, vp, vp, vp]
+        l.hs_rows_gather.argtypes = [vp, vp, vp, i32, i32, vp]
+        l.hs_rows_scatter_add.argtypes = [vp, vp, vp, i32, i32, vp, i32, i32, vp]
+        l.hs_rows_scatter_add_bwd.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, vp]
         l.hs_moe_gate_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
         l.hs_moe_combine_fwd.argtypes = [vp, C.POINTER(vp), vp, i32, i32, i32, vp]
         l.hs_moe_combine_bwd.argtypes = [vp, C.POINTER(vp), vp, C.POINTER(vp), vp, i32, i32, i32, vp]
@@ -108,11 +112,16 @@ def kan_linear(x, grid, base_weight, spline_weight, spline_scaler, grid_size, sp
 
 
 class MoEGateFn(Function):
-    """x -> (gates (B,E), aux loss) with w_gate / w_noise; noisy top-k in training (our RNG), plain top-k in eval."""
+    """x -> (gates (B,E), aux loss) with w_gate / w_noise; noisy top-k in training, plain top-k in eval.  `noise`: optional
+    (B,E) standard-normal draw (the reference's torch.randn_like(clean_logits), moe.py:247); None draws from the counter RNG."""
 
     @staticmethod
-    def forward(ctx, x, w_gate, w_noise, k, noisy, coef):
+    def forward(ctx, x, w_gate, w_noise, k, noisy, coef, noise=None):
         x, w_gate, w_noise = _f32c(x), _f32c(w_gate), _f32c(w_noise)
+        if noise is not None:
+            noise = _f32c(noise)
+            if tuple(noise.shape) != (x.shape[0], w_gate.shape[1]):
+                raise ValueError(f"MoE gating noise must be (batch, experts) = {(x.shape[0], w_gate.shape[1])}, got {tuple(noise.shape)}")
         B, in_f = x.shape
         E = w_gate.shape[1]
         dev = x.device
@@ -133,7 +142,7 @@ class MoEGateFn(Function):
         d_imp = torch.empty(E, dtype=torch.float32, device=dev)
         d_load = torch.empty(E, dtype=torch.float32, device=dev)
         seed = rt.next_seed() if noisy else 0
-        L.check(lib.hs_moe_gate_fwd(rt.p(clean), rt.p(rawn), B, E, k, 1 if noisy else 0, 1e-2, seed, coef, rt.p(gates), rt.p(p),
+        L.check(lib.hs_moe_gate_fwd(rt.p(clean), rt.p(rawn), rt.p(noise) if noisy else None, B, E, k, 1 if noisy else 0, 1e-2, seed, coef, rt.p(gates), rt.p(p),
                                     rt.p(top), rt.p(z), rt.p(sigma), rt.p(loadrow), rt.p(loss), rt.p(d_imp), rt.p(d_load),
                                     rt.stream()), "hs_moe_gate_fwd")
         ctx.save_for_backward(x, w_gate, w_noise, clean, rawn, p, top, z, sigma, d_imp, d_load)
@@ -168,7 +177,84 @@ class MoEGateFn(Function):
             raw.gemm(d_clean, w_gate, dx, B, in_f, E, a_kind=L.A_KC, b_kind=L.B_KC, lda=E, ldb=E)
             if noisy:
                 raw.gemm(d_raw, w_noise, dx, B, in_f, E, a_kind=L.A_KC, b_kind=L.B_KC, lda=E, ldb=E, accumulate=True)
-        return dx, d_wg, d_wn, None, None, None
+        return dx, d_wg, d_wn, None, None, None, None
+
+
+def moe_dispatch_index(gates):
+    """-> (idx (E,B) int32: idx[e, :count[e]] = rows with gates[:, e] > 0 ascending, counts as a Python list).  The counts
+    come back to the host -- the reference's SparseDispatcher does the same (`.tolist()`, moe.py:60): the experts' batch
+    sizes are data-dependent launch shapes."""
+    gates = _f32c(gates.detach())
+    B, E = gates.shape
+    idx = torch.empty((E, B), dtype=torch.int32, device=gates.device)
+    cnt = torch.empty(E, dtype=torch.int32, device=gates.device)
+    L.check(_l().hs_moe_dispatch_index(rt.p(gates), B, E, rt.p(idx), rt.p(cnt), rt.stream()), "hs_moe_dispatch_index")
+    return idx, cnt.tolist()
+
+
+class RowsGatherFn(Function):
+    """x (B,D), idx (n,) int32 unique -> x[idx] (n,D); backward adds the rows' gradients back into a (B,D) zero tensor."""
+
+    @staticmethod
+    def forward(ctx, x, idx, n):
+        x = _f32c(x)
+        out = torch.empty((n, x.shape[1]), dtype=torch.float32, device=x.device)
+        L.check(_l().hs_rows_gather(rt.p(x), rt.p(idx), rt.p(out), n, x.shape[1], rt.stream()), "hs_rows_gather")
+        ctx.save_for_backward(idx)
+        ctx.meta = (x.shape[0], n)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        B, n = ctx.meta
+        dout = _f32c(dout)
+        dx = torch.zeros((B, dout.shape[1]), dtype=torch.float32, device=dout.device)
+        L.check(_l().hs_rows_scatter_add(rt.p(dx), rt.p(idx), None, 0, 0, rt.p(dout), n, dout.shape[1], rt.stream()),
+                "hs_rows_scatter_add")
+        return dx, None, None
+
+
+class MoESparseCombineFn(Function):
+    """y[b] = sum over the experts e that row b was dispatched to of gates[b, e] * out_e[position of b in e's batch]
+    (SparseDispatcher.combine, moe.py:86-103: stitched * nonzero gates, index_add).  Experts are added in index order and a
+    row occurs once per expert, so the sum is deterministic."""
+
+    @staticmethod
+    def forward(ctx, gates, idx, counts, B, *outs):
+        gates = _f32c(gates)
+        outs = [_f32c(o) for o in outs]
+        O = outs[0].shape[1] if outs else 0
+        for o in outs:
+            if o.shape[0]:
+                O = o.shape[1]
+        y = torch.zeros((B, O), dtype=torch.float32, device=gates.device)
+        E = gates.shape[1]
+        lib = _l()
+        for e, (o, n) in enumerate(zip(outs, counts)):
+            if n:
+                L.check(lib.hs_rows_scatter_add(rt.p(y), rt.p(idx[e]), rt.p(gates), E, e, rt.p(o), n, O, rt.stream()),
+                        "hs_rows_scatter_add")
+        ctx.save_for_backward(gates, idx, *outs)
+        ctx.counts = counts
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        gates, idx, *outs = ctx.saved_tensors
+        counts = ctx.counts
+        dy = _f32c(dy)
+        E = gates.shape[1]
+        dgates = torch.zeros_like(gates)
+        douts = []
+        lib = _l()
+        for e, (o, n) in enumerate(zip(outs, counts)):
+            d = torch.empty_like(o)
+            if n:
+                L.check(lib.hs_rows_scatter_add_bwd(rt.p(dy), rt.p(idx[e]), rt.p(gates), E, e, rt.p(o), rt.p(d), rt.p(dgates), n,
+                                                    o.shape[1], rt.stream()), "hs_rows_scatter_add_bwd")
+            douts.append(d)
+        return (dgates, None, None, None, *douts)
 
 
 class MoECombineFn(Function):

@@ -162,6 +162,30 @@ def gen_kan_moe():
     ((y * cot).sum() + 3.0 * aux).backward()
     save("moe_eval", out=y, aux=aux, cot=cot, inp={"x": x}, gin={"x": xi.grad},
          gw={k: p.grad for k, p in m.named_parameters() if p.grad is not None})
+    # TRAIN mode (noisy top-k gating, moe.py:231-265, and the normal-CDF load estimate, :198-229): the only random draw of the
+    # forward is torch.randn_like(clean_logits) (:247).  It is recorded by drawing it first under the same seed: randn of the
+    # same shape / dtype from the same CPU generator state is the same tensor.
+    xt = rnd((24, 16), 53, 0.7)
+    m = moe.MoE(16, 5, num_experts=4, hidden_size=8, k=2, layers_hidden=[16, 24, 5])
+    load_procedural(m, SEED + 84)
+    with torch.no_grad():          # procedural w_noise is small: scale it up so the noise decides some of the top-k picks
+        m.w_noise.mul_(3.0)
+    m.train()
+    torch.manual_seed(SEED + 85)
+    noise = torch.randn(24, 4)
+    torch.manual_seed(SEED + 85)
+    xi = xt.clone().requires_grad_(True)
+    gates, load = m.noisy_top_k_gating(xi, True)
+    torch.manual_seed(SEED + 85)
+    y, aux = m(xi)
+    cot = rnd(tuple(y.shape), SEED + 86)
+    ((y * cot).sum() + 3.0 * aux).backward()
+    assert m.w_noise.grad is not None and m.w_noise.grad.abs().max() > 0
+    clean_top = (xt @ m.w_gate).softmax(1).topk(2, dim=1).indices.sort(1).values
+    noisy_top = (gates > 0).nonzero()[:, 1].view(24, 2)
+    assert (clean_top != noisy_top).any(), "the noise should change at least one top-k decision"
+    save("moe_train_noisy", out=y, aux=aux, cot=cot, noise=noise, gates=gates.detach(), load=load.detach(), inp={"x": xt},
+         gin={"x": xi.grad}, gw={k: p.grad for k, p in m.named_parameters() if p.grad is not None})
 
 
 def gen_kan_update_grid():

@@ -51,6 +51,30 @@ def test_oracle_moe_matches_reference_vectors():
         _close(params[k].grad, g, f"moe grad {k}", rtol=1e-4)
 
 
+def test_oracle_moe_train_mode_matches_reference_vectors():
+    """noisy top-k gating + normal-CDF load estimate (reference moe.py:198-265) with the recorded torch.randn_like draw:
+    gates, load, aux loss, outputs and every gradient incl. w_noise"""
+    fx = gc.load("moe_train_noisy")
+    m = load_procedural(om.OMoE(16, 5, 4, 2, [16, 24, 5]), gc.SEED + 84)
+    with torch.no_grad():
+        m.w_noise.mul_(3.0)
+    m.train()
+    x = fx["inp"]["x"].clone().requires_grad_(True)
+    gates, load = m.gating(x, fx["noise"])
+    _close(gates, fx["gates"], "moe train gates")
+    _close(load, fx["load"], "moe train load")
+    assert torch.equal(gates > 0, fx["gates"] > 0), "top-k decisions"
+    y, aux = m(x, noise=fx["noise"])
+    _close(y, fx["out"], "moe train out")
+    _close(aux, fx["aux"], "moe train aux loss")
+    ((y * fx["cot"]).sum() + 3.0 * aux).backward()
+    _close(x.grad, fx["gin"]["x"], "moe train dx", rtol=1e-4)
+    params = dict(m.named_parameters())
+    assert "w_noise" in fx["gw"]
+    for k, g in fx["gw"].items():
+        _close(params[k].grad, g, f"moe train grad {k}", rtol=1e-4)
+
+
 def test_kl_divergence_vector():
     fx = gc.load("kl_divergence")
     _close(om.okl(fx["p"], fx["q"]), fx["kl"], "kl")

@@ -368,12 +368,67 @@ def test_moe_eval_matches_reference_vectors():
     for k, g in fx["gw"].items():
         assert params[k].grad is not None, k
         _close(params[k].grad, g, f"moe grad {k}", 5e-4, 1e-6)
-    # training mode: noisy gating runs, is finite, and produces gradients for w_noise as well
-    m.train()
+
+
+def test_moe_train_mode_matches_reference_vectors():
+    """TRAIN mode -- the mode the per-batch training path runs: noisy top-k gating and the normal-CDF load estimate (reference
+    moe.py:198-265) with the reference's own torch.randn_like draw fed to the gate kernel (hs_moe_gate_fwd `noise`), sparse
+    dispatch (moe.py:48-112).  Gates, top-k decisions, aux loss, outputs and all gradients incl. w_noise against vectors
+    made by running the reference MoE in train mode (oracle/gen_golden.py:gen_kan_moe)."""
+    from ConNexT.models.block.moe import MoE, SparseDispatcher
+    from hamspine import kan as K
+    fx = gc.load("moe_train_noisy")
+    m = load_procedural(MoE(16, 5, num_experts=4, hidden_size=8, k=2, layers_hidden=[16, 24, 5]), gc.SEED + 84)
+    with torch.no_grad():
+        m.w_noise.mul_(3.0)
+    m = m.to(DEV).train()
+    x = fx["inp"]["x"].to(DEV).requires_grad_(True)
+    gates, _ = K.MoEGateFn.apply(x, m.w_gate, m.w_noise, 2, True, 1e-2, fx["noise"].to(DEV))
+    _close(gates, fx["gates"], "moe train gates", 1e-5, 1e-7)
+    assert torch.equal((gates > 0).cpu(), fx["gates"] > 0), "noisy top-k decisions differ from the reference"
+    # the dispatcher hands each expert exactly the rows the reference's does (ascending batch index), k/E of the batch in all
+    d = SparseDispatcher(4, gates)
+    want_rows = [(fx["gates"][:, e] > 0).nonzero().flatten().tolist() for e in range(4)]
+    assert d._part_sizes == [len(r) for r in want_rows] and sum(d._part_sizes) == 2 * x.shape[0]
+    for e in range(4):
+        assert d._idx[e, :d._part_sizes[e]].tolist() == want_rows[e], f"rows of expert {e}"
+        assert torch.equal(d.dispatch(x)[e], x[want_rows[e]]), f"dispatched rows of expert {e}"
+        _close(d.expert_to_gates()[e], fx["gates"][want_rows[e], e], f"nonzero gates of expert {e}", 1e-5, 1e-7)
+    m.gating_noise = fx["noise"].to(DEV)
+    y, aux = m(x)
+    assert m.gating_noise is None
+    _close(y, fx["out"], "moe train out", 1e-4)
+    _close(aux, fx["aux"], "moe train aux (importance + load cv^2)", 1e-4)
+    ((y * fx["cot"].to(DEV)).sum() + 3.0 * aux).backward()
+    _close(x.grad, fx["gin"]["x"], "moe train dx", 5e-4, 1e-6)
+    params = dict(m.named_parameters())
+    assert "w_noise" in fx["gw"] and "w_gate" in fx["gw"]
+    for k, g in fx["gw"].items():
+        assert params[k].grad is not None, k
+        _close(params[k].grad, g, f"moe train grad {k}", 5e-4, 1e-6)
+    # without a supplied draw the counter RNG is used: deterministic per seed, different between calls
     m.zero_grad(set_to_none=True)
+    y1, _ = m(x)
+    y2, _ = m(x)
+    assert torch.isfinite(y1).all() and not torch.equal(y1, y2)
+
+
+def test_moe_expert_without_rows_gets_zero_gradients():
+    """an expert no row is dispatched to: the reference runs it on an empty batch (zero gradients, not None)"""
+    from ConNexT.models.block.moe import MoE
+    m = load_procedural(MoE(16, 5, num_experts=4, hidden_size=8, k=1, layers_hidden=[16, 24, 5]), gc.SEED + 82)
+    with torch.no_grad():
+        m.w_gate.zero_()
+        m.w_gate[:, 2] = 0.0
+        m.w_gate[0, 1] = 5.0          # x[:, 0] > 0 for every row below -> expert 1 wins every row
+    m = m.to(DEV).eval()
+    x = torch.rand(8, 16, device=DEV) + 0.5
     y, aux = m(x)
     (y.sum() + aux).backward()
-    assert torch.isfinite(y).all() and torch.isfinite(aux) and torch.isfinite(m.w_noise.grad).all()
+    assert torch.isfinite(y).all()
+    g0 = m.experts[0].layers[0].base_weight.grad
+    assert g0 is not None and float(g0.abs().max()) == 0.0
+    assert float(m.experts[1].layers[0].base_weight.grad.abs().max()) > 0.0
 
 
 def test_supcon_matches_oracle():

@@ -1,0 +1,86 @@
+"""The baseline family's training / validation loop replayed with the STOCK pieces the reference's script uses, on the
+product model (missing item 6).
+
+reference scripts/train.py: `criterion = nn.CrossEntropyLoss(weight=..., label_smoothing=0.02)` (:238-254), `torch.optim.AdamW`
+(:257-261), the LambdaLR warm-up + cosine schedule stepped per batch (:311-336, :385), one training step =
+zero_grad -> forward_features -> classifier -> criterion -> backward -> optimizer.step (:362-385), then `validate()` under
+`model.eval()` / `torch.no_grad()` calling `model(images, ids, mask, tabular_input=...)` and arg-maxing the logits (:103-128).
+None of these are hamspine objects: the product model has to work with torch's own loss module, optimizer and scheduler.
+The same loop runs on the CPU oracle with identical weights and data; f32 mode, dropout 0 (train-mode dropout cannot share
+torch's RNG stream)."""
+import math
+import os
+
+import pytest
+import torch
+import torch.nn as nn
+
+import golden_cases as gc
+
+pytestmark = pytest.mark.gpu
+
+import hamspine  # noqa: E402
+from oracle import models as om  # noqa: E402
+from oracle.procedural import load_procedural, synthetic_batch  # noqa: E402
+
+
+def _loop(model, device, batches, val_batches, steps_lr):
+    """scripts/train.py:349-395 + validate() :103-128, verbatim in structure"""
+    criterion = nn.CrossEntropyLoss(label_smoothing=0.02)                                   # train.py:240
+    optimizer = torch.optim.AdamW(model.parameters(), lr=2e-3, weight_decay=0.01)           # train.py:257-261
+    warm, total = steps_lr
+
+    def lr_lambda(step):                                                                     # train.py:318-324
+        if step < warm:
+            return float(step + 1) / float(max(1, warm))
+        progress = (step - warm) / float(max(1, total - warm))
+        return 0.5 * (1.0 + math.cos(math.pi * min(1.0, progress)))
+    scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda)
+    losses = []
+    model.train()
+    for images, ids, mask, labels in batches:
+        images, ids, mask, labels = images.to(device), ids.to(device), mask.to(device), labels.to(device)
+        optimizer.zero_grad()
+        features = model.forward_features(images, ids, mask, tabular_input=None, ablation_mode=None)
+        logits = model.classifier(features)
+        loss = criterion(logits, labels)
+        loss.backward()
+        optimizer.step()
+        scheduler.step()
+        losses.append(loss.item())
+    model.eval()
+    total_loss, correct, count, preds = 0.0, 0, 0, []
+    with torch.no_grad():
+        for images, ids, mask, labels in val_batches:
+            images, ids, mask, labels = images.to(device), ids.to(device), mask.to(device), labels.to(device)
+            logits = model(images, ids, mask, tabular_input=None)
+            total_loss += criterion(logits, labels).item()
+            _, predicted = torch.max(logits.data, 1)
+            count += labels.size(0)
+            correct += (predicted == labels).sum().item()
+            preds.append(predicted.cpu())
+    return losses, total_loss / len(val_batches), 100 * correct / count, torch.cat(preds)
+
+
+@pytest.mark.parametrize("case", ["e2e_basic_mlp", "e2e_multiscale_residual"])
+def test_baseline_train_and_validate_loop_with_stock_torch_pieces(case, tmp_path):
+    import model as product_model
+    seed, kw = gc.E2E_CASES[case]
+    batches = [synthetic_batch(4, 64, 24, gc.TINY_BERT["vocab_size"], 7, seed=900 + i, min_len=3) for i in range(4)]
+    val = [synthetic_batch(4, 64, 24, gc.TINY_BERT["vocab_size"], 7, seed=950 + i, min_len=3) for i in range(2)]
+    oracle = load_procedural(om.OMultimodalBaselineModel(bert_cfg=gc.TINY_BERT, **gc.E2E_COMMON, **kw), seed)
+    ref = _loop(oracle, "cpu", batches, val, (2, 4))
+    hamspine.set_compute_dtype("f32")
+    try:
+        d = gc.save_bert_dir(gc.TINY_BERT, os.path.join(str(tmp_path), "bert"))
+        m = product_model.MultimodalBaselineModel(pretrained_image=False, image_weights_path=None, text_model_name=d,
+                                                  **gc.E2E_COMMON, **kw)
+        load_procedural(m, seed)
+        got = _loop(m.to("cuda"), "cuda", batches, val, (2, 4))
+    finally:
+        hamspine.set_compute_dtype("bf16")
+    # four AdamW steps at lr up to 2e-3 amplify f32 summation-order differences: 2e-3 on the later losses
+    for i, (a, b) in enumerate(zip(got[0], ref[0])):
+        assert abs(a - b) <= (1e-4 if i == 0 else 2e-3) * max(abs(b), 1.0), f"{case}: train loss of step {i}: {a} vs {b}"
+    assert abs(got[1] - ref[1]) <= 2e-3 * max(abs(ref[1]), 1.0), f"{case}: validation loss {got[1]} vs {ref[1]}"
+    assert got[2] == ref[2] and torch.equal(got[3], ref[3]), f"{case}: validation predictions / accuracy differ"
