@@ -27,7 +27,7 @@ from oracle.procedural import load_procedural, synthetic_batch  # noqa: E402
 def _loop(model, device, batches, val_batches, steps_lr):
     """scripts/train.py:349-395 + validate() :103-128, verbatim in structure"""
     criterion = nn.CrossEntropyLoss(label_smoothing=0.02)                                   # train.py:240
-    optimizer = torch.optim.AdamW(model.parameters(), lr=2e-3, weight_decay=0.01)           # train.py:257-261
+    optimizer = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01)           # train.py:257-261 (lr: config.yml)
     warm, total = steps_lr
 
     def lr_lambda(step):                                                                     # train.py:318-324
@@ -79,7 +79,9 @@ def test_baseline_train_and_validate_loop_with_stock_torch_pieces(case, tmp_path
         got = _loop(m.to("cuda"), "cuda", batches, val, (2, 4))
     finally:
         hamspine.set_compute_dtype("bf16")
-    # four AdamW steps at lr up to 2e-3 amplify f32 summation-order differences: 2e-3 on the later losses
+    # Adam turns a gradient at rounding-noise level into a full +-lr update whose SIGN the rounding decides, so two exact-f32
+    # implementations drift apart step by step (at lr 2e-3 the fourth loss of this tiny batch-4, train-mode-BatchNorm model
+    # already differs by 2.5 %); at the reference's lr 1e-4 the drift over four steps stays below 2e-3
     for i, (a, b) in enumerate(zip(got[0], ref[0])):
         assert abs(a - b) <= (1e-4 if i == 0 else 2e-3) * max(abs(b), 1.0), f"{case}: train loss of step {i}: {a} vs {b}"
     assert abs(got[1] - ref[1]) <= 2e-3 * max(abs(ref[1]), 1.0), f"{case}: validation loss {got[1]} vs {ref[1]}"
