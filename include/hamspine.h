@@ -488,6 +488,16 @@ hs_status hs_moe_combine_fwd(const float* gates, const float* const* outs, float
 hs_status hs_moe_combine_bwd(const float* gates, const float* const* outs, const float* dy, float* const* douts,
                              float* dgates, int32_t B, int32_t E, int32_t O, void* stream);
 
+/* Streaming 1x1 convolution of the image tower (csrc/pw_stream.hip; reference: torchvision Bottleneck conv1 / conv3 / downsample
+   + train-mode BatchNorm, encoder.py:35-58, mibf_net/model_resnet.py:15): y[M][N] = x[M][K] . w[N][K]^T in bf16 with f32
+   accumulation, persistent workgroups over 64-row blocks.  stats (optional): hs_pointwise_stat_rows(M, N, K) rows of
+   (count, mean, M2) per output channel -- the partials hs_bn_params.partial_rows consumes.  Covered shapes: K % 64 == 0,
+   64 <= K <= 256, N % 128 == 0 or N == 64.  A measured alternative to hs_gemm for these layers (not faster end to end: see
+   the kernel's header); the composite executors use it only under HAMSPINE_PW_STREAM=1. */
+int32_t hs_pointwise_stat_rows(int64_t M, int32_t N, int32_t K);
+hs_status hs_pointwise_fwd(const void* x, int64_t M, int32_t K, int32_t ldx, const void* w, int32_t N, void* y, int32_t ldy,
+                           float* stats, void* stream);
+
 /* Sparse dispatch (SparseDispatcher, moe.py:48-112: expert e sees only the rows with gates[b][e] > 0, i.e. k/E of the work).
    hs_moe_dispatch_index: idx[e*B + 0 .. count[e]) = those rows, ascending.  hs_rows_gather: dst[i] = src[idx[i]] (rows of D
    floats).  hs_rows_scatter_add: dst[idx[i]] += scale[idx[i]*ld_scale + col] * src[i] (scale may be NULL; idx unique, so the

@@ -262,6 +262,9 @@ def _declare(l):
     l.hs_stage_images_u8.argtypes = [vp, vp, i32, i32, i32, P(f32), P(f32), vp]
     l.hs_set_overlap.restype = None
     l.hs_grad_milestones.argtypes = [i32, P(vp), P(vp)]
+    l.hs_pointwise_stat_rows.argtypes = [i64, i32, i32]
+    l.hs_pointwise_stat_rows.restype = i32
+    l.hs_pointwise_fwd.argtypes = [vp, i64, i32, i32, vp, i32, vp, i32, vp, vp]
     l.hs_measure_build.argtypes = []
     l.hs_measure_build.restype = i32
     l.hs_set_wgrad_nt.argtypes = [i32]

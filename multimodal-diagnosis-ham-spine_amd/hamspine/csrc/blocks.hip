@@ -8,6 +8,7 @@
 #include <unordered_map>
 #include <stdlib.h>
 #include "hs_common.h"
+#include "pw_stream.h"
 
 namespace hs {
 
@@ -692,6 +693,29 @@ static bool bn_finish_enabled() {     // HAMSPINE_BN_FINISH=0: BatchNorm finishe
 // bn (optional, with stats): the BatchNorm that follows; when the launch can it finishes the statistics too (bn->stats_done)
 static int conv_fwd_run(Run& r, const ConvShape& s, const void* x, const void* w_c, void* y, float* stats = nullptr,
                         int* stat_rows = nullptr, const FoldedBn* fold = nullptr, hs_bn_params* bn = nullptr) {
+    // optional: 1x1 convolutions of a training step through the streaming kernel (pw_stream.hip: persistent workgroups,
+    // A-stationary row blocks, one partial statistics row per workgroup; the BatchNorm finishes them in its own small launch)
+    static const bool pw_on = [] { const char* e = getenv("HAMSPINE_PW_STREAM"); return e && e[0] == '1'; }();   // measured: a wash, off
+    if (pw_on && !fold && is_pointwise(s) && r.dt == HS_BF16 && stats && stat_rows && fused_bn_stats_enabled()) {
+        const long long Mo = (long long)s.N * s.P * s.Q;
+        const PwPlan pl = pw_stream_plan(Mo, s.Cout, s.Cin, true);
+        if (pl.ok) {
+            *stat_rows = pl.stat_rows;
+            if (!r.plan) {
+                PwArgs a;
+                memset(&a, 0, sizeof(a));
+                a.A = (const char*)x; a.W = (const char*)w_c; a.D = (char*)y;
+                a.a_bytes = (unsigned long long)Mo * s.Cin * 2;
+                a.w_bytes = (unsigned long long)s.Cout * s.Cin * 2;
+                a.lda = s.Cin; a.ldd = s.Cout;
+                a.M = (int)Mo; a.N = s.Cout; a.K = s.Cin;
+                a.nblocks = (int)((Mo + 63) / 64);
+                a.stats = stats;
+                HS_PROPAGATE(pw_stream_run(pl, a, r.s));
+            }
+            return HS_OK;
+        }
+    }
     hs_gemm_params p = gemm_defaults(r.dt);
     if (fold) {
         p.colscale = fold->scale;

@@ -131,3 +131,15 @@ def gemm(A, B, D, M, N, K, a_kind=L.A_KC, b_kind=L.B_KC, lda=0, ldb=0, ldd=None,
 
 def suggest_split(M, N, K, dtype):
     return int(L.lib().hs_gemm_suggest_split(M, N, K, dtype))
+
+
+def pointwise_fwd(x, w, want_stats=True):
+    """streaming 1x1 convolution (hs_pointwise_fwd): x [M][K] bf16, w [N][K] bf16 -> (y [M][N] bf16, stats [(rows)][N][3] or None)"""
+    need_gpu(x, w)
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    rows = int(L.lib().hs_pointwise_stat_rows(M, N, K)) if want_stats else 0
+    stats = torch.full((max(rows, 1), N, 3), float("nan"), dtype=torch.float32, device=x.device) if want_stats else None
+    L.check(L.lib().hs_pointwise_fwd(ptr(x), M, K, x.stride(0), ptr(w), N, ptr(y), N, ptr(stats), stream_ptr()), "hs_pointwise_fwd")
+    return y, (stats[:rows] if want_stats else None)

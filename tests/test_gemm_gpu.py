@@ -521,3 +521,44 @@ def test_p8_body_is_what_bert_sized_projections_run():
     raw.gemm(A.to(DEV), B.to(DEV), D, M, N, K, lda=K, ldb=K, bias=bias.to(DEV))
     ref = A.double() @ B.double().t() + bias.double()
     assert (D.cpu().double() - ref).abs().max() <= 2.0 ** -7 * ref.abs().max()
+
+
+# ---- streaming 1x1 convolution (csrc/pw_stream.hip) ---------------------------------------------------------------------------
+def _merge_stats(st):
+    """(count, mean, M2) partial rows -> per-channel mean and biased variance (Chan), in float64"""
+    st = st.double().cpu()
+    n = st[:, :, 0]
+    tot = n.sum(0)
+    mean = (n * st[:, :, 1]).sum(0) / tot
+    m2 = (st[:, :, 2] + n * (st[:, :, 1] - mean) ** 2).sum(0)
+    return tot, mean, m2 / tot
+
+
+PW_SHAPES = [(100352, 256, 64), (100352, 64, 256), (100352, 64, 64), (100352, 128, 256), (25088, 512, 128), (6272, 1024, 256),
+             (1000, 64, 64), (200, 128, 192), (1568, 2048, 256), (4160, 256, 128)]
+
+
+@pytest.mark.parametrize("M,N,K", PW_SHAPES)
+def test_streaming_pointwise_conv_matches_float64(M, N, K):
+    """every 1x1 shape class of ResNet50 at batch 32 (rows x out x in), plus ragged row counts (tail block, fewer row blocks
+    than workgroups): integer data -> the bf16 result and the column statistics are exact"""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randint(-3, 4, (M, K), generator=g).float().bfloat16()
+    w = torch.randint(-2, 3, (N, K), generator=g).float().bfloat16()
+    ref = x.double() @ w.double().t()
+    assert ref.abs().max() < 256 * 8          # exactly representable after the bf16 rounding of the result? no: compare rounded
+    y, st = raw.pointwise_fwd(x.to(DEV), w.to(DEV))
+    assert torch.equal(y.cpu().double(), ref.bfloat16().double()), "result"
+    assert st.shape[0] == int(L.lib().hs_pointwise_stat_rows(M, N, K)) and torch.isfinite(st).all()
+    tot, mean, var = _merge_stats(st)
+    assert torch.equal(tot, torch.full((N,), float(M), dtype=torch.float64)), "every row counted once"
+    assert (mean - ref.mean(0)).abs().max() <= 1e-5 * max(ref.abs().max().item(), 1.0)
+    assert (var - ref.var(0, unbiased=False)).abs().max() <= 1e-4 * max(ref.var(0, unbiased=False).max().item(), 1.0)
+    # random data: agreement with the tiled GEMM body to bf16 rounding of the result
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.1).bfloat16()
+    y, st = raw.pointwise_fwd(x.to(DEV), w.to(DEV))
+    ref = x.double() @ w.double().t()
+    assert (y.cpu().double() - ref).abs().max() <= 2.0 ** -7 * ref.abs().max()
+    tot, mean, var = _merge_stats(st)
+    assert (var - ref.var(0, unbiased=False)).abs().max() <= 1e-3 * ref.var(0, unbiased=False).max()
