@@ -290,15 +290,26 @@ def gpu_leg(args, rank, world, local_rank):
     achieved = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
     # HBM traffic per launch of the same kernel family: PMC counters need their own rocprofv3 passes (FETCH_SIZE and
     # WRITE_SIZE cannot share one on gfx950), so the figure is read from the committed summary of those passes
-    traffic, traffic_src = None, None
-    for cand in ("round2_pmc_traffic.json", "round1_pmc_traffic.json"):
-        tpath = os.path.join(ROOT, "profiles", cand)
-        if args.workload == "c2" and os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
+    # The file carries the build id (hash of the kernel sources) it was measured on: a figure from another build is not
+    # reported (null) instead of going stale silently.
+    traffic, traffic_src, traffic_by_class = None, None, None
+    tpath = os.path.join(ROOT, "profiles", "round3_pmc_traffic.json")
+    if args.workload == "c2" and os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        try:
+            from pmc_traffic import build_id
+            here = build_id()
+        except Exception:      # noqa: BLE001
+            here = None
+        if here is not None and tj.get("build_id") == here:
             traffic = round(tj["traffic_bytes_per_launch"])
-            traffic_src = f"profiles/{cand}: " + tj["method"]
-            break
+            traffic_src = f"profiles/round3_pmc_traffic.json (build {here}): " + tj["method"]
+            traffic_by_class = {k: v["ratio"] for k, v in tj.get("by_class", {}).items()} or None
+        else:
+            traffic_src = (f"profiles/round3_pmc_traffic.json was measured on build {tj.get('build_id')}, this is build {here}: "
+                           "not reported (re-run tools/final_profiles.sh)")
     roofline = {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -308,6 +319,7 @@ def gpu_leg(args, rank, world, local_rank):
         "kernel_ms_per_step": round(fam_ms / prof_steps, 3),
         "algorithmic_tflop_per_step": round(fam_flops / prof_steps / 1e12, 3),
         "traffic_unit": "bytes per launch (PMC, separate passes)", "traffic_source": traffic_src,
+        "traffic_over_algorithmic_by_class": traffic_by_class,
         "timing": "HIP events around every launch of the family on its own stream, 2 steps run without stream overlap; "
                   "the same bracket around an empty kernel reads event_bracket_us (not subtracted from avg_launch_us)",
         "event_bracket_us": round(bracket_us.value, 2),
@@ -460,11 +472,15 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--seq-len", type=int, default=128, help="caption length (the reference's MIBF loader pads to 256, "
+                    "mibf_net/dataset_spine.py:88; the metric of BASELINE.json is quoted at 128)")
     ap.add_argument("--gemm-log", default=None, help="copy the per-launch CSV of the roofline leg to this file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-f32 mode leg")
     ap.add_argument("--no-ddp-config", action="store_true", help="skip the N=1 leg that runs the data-parallel configuration")
     args = ap.parse_args()
+    global SEQ
+    SEQ = args.seq_len
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -480,6 +496,13 @@ def main():
         else:
             dist.init_process_group(backend)
     batch, classes, train_tflop, desc = WORKLOADS[args.workload]
+    if SEQ != 128:
+        # SURVEY 8d counts at L = 128; BERT-base is 10.874 GMAC/sample of projections + FFN (linear in L) and 0.300 of attention
+        # (quadratic): 22.951 GMAC at L = 256.  Train FLOPs = 3 x forward, 1 MAC = 2 FLOP.
+        gmac = lambda L: 10.874 * (L / 128.0) + 0.300 * (L / 128.0) ** 2
+        train_tflop = train_tflop + 3 * 2 * (gmac(SEQ) - gmac(128)) * batch / 1000.0
+        WORKLOADS[args.workload] = (batch, classes, train_tflop, desc.replace("L=128", f"L={SEQ}") + f" [caption length {SEQ}]")
+        desc = WORKLOADS[args.workload][3]
     # a line measured with work left out is invalid: the work-skipping switch of tools/knockout.sh exists only in
     # -DHS_MEASURE builds of the library, and this script refuses both the variable and such a build
     if os.environ.get("HAMSPINE_KNOCKOUT", "0") not in ("", "0"):

@@ -1373,7 +1373,10 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
     char* tA_qkv = grouped ? (char*)r.ws.alloc(M * 3ll * Hd * 2) : tA;
     r.group_nt = grouped;
     if (grouped && !r.plan) {
-        r.grp_nt = gemm_group_open(r.s, (long long)(uintptr_t)d.q.dw);      // one cached problem table per layer (keyed by its dWq)
+        // one cached problem table per layer, keyed by the layer's WEIGHT pointer: stable across steps (a gradient pointer is
+        // not -- models that allocate fresh gradient memory per backward would add a table per address -- and is NULL for a
+        // frozen weight, which would collide with the image tower's slots 0 / 1); + 16 keeps it clear of slots -1, 0, 1
+        r.grp_nt = gemm_group_open(r.s, (long long)(uintptr_t)d.q.w + 16);
         HS_REQUIRE(r.grp_nt != nullptr, "bert_layer_bwd: cannot set up the grouped weight-gradient launch");
     }
     // X^T of the four saved activations the weight gradients read: all known when the layer's backward starts, so they are

@@ -266,13 +266,18 @@ class ResNetTowerFn(Function):
         ctx.counted = _forward_begins(ent, needs)
         if DEBUG_KEEP is not None:
             DEBUG_KEEP.append((ent, saved))
+        # the outputs are views into the arena the backward reads (ReLU masks, BatchNorm inputs): registering them makes
+        # autograd's version counters catch a consumer that modifies one in place (it would corrupt the backward silently)
+        ctx.save_for_backward(*outs)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *dys):
         ent, saved, params = ctx.ent, ctx.saved_buf, ctx.params
         if saved is None:
-            raise RuntimeError("hamspine.tower: backward through a tower a second time (its saved activations were freed)")
+            raise RuntimeError("hamspine.tower: backward through a tower a second time: its saved activations are freed by the "
+                               "first backward (retain_graph=True is not supported on the tower nodes)")
+        _ = ctx.saved_tensors                        # raises if an output was modified in place since the forward
         n = len(ent.taps)
         ptrs = (C.c_void_p * n)()
         keep = []
@@ -456,13 +461,16 @@ class BertTowerFn(Function):
         ctx.ent, ctx.saved_buf, ctx.seed = ent, saved, seed
         ctx.ids, ctx.mask, ctx.params = ids, mask, params
         ctx.counted = _forward_begins(ent, needs)
+        ctx.save_for_backward(out)                   # a view into the arena: in-place edits by a consumer are caught at backward
         return out
 
     @staticmethod
     def backward(ctx, dy):
         ent, saved, params = ctx.ent, ctx.saved_buf, ctx.params
         if saved is None:
-            raise RuntimeError("hamspine.tower: backward through a tower a second time (its saved activations were freed)")
+            raise RuntimeError("hamspine.tower: backward through a tower a second time: its saved activations are freed by the "
+                               "first backward (retain_graph=True is not supported on the tower nodes)")
+        _ = ctx.saved_tensors
         dy = dy.contiguous()
         if dy.dtype != ent.dtype:
             dy = dy.to(ent.dtype)

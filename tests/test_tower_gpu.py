@@ -282,3 +282,24 @@ def test_grouped_weight_gradients_of_an_mlp_equal_separate_launches():
         # hidden gradient differs by its bf16 rounding (the fused node rounds gelu' * (dy W2) once, the two nodes twice)
         tol = 2e-5 if nme in ("dw2", "db2") else 2e-2
         assert (a - b).abs().max().item() <= tol * b.abs().max().item() + 1e-6, nme
+
+
+def test_tower_outputs_are_guarded_against_in_place_edits(tmp_path):
+    """the tower's outputs are views into the arena its backward reads (round-2 advisor finding): a consumer that modifies
+    one in place must get autograd's version-counter error instead of silently corrupted gradients; a second backward
+    through the same graph is refused with a clear message"""
+    from hamspine.nn import BertConfig, BertModel
+    cfg = BertConfig(vocab_size=100, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                     max_position_embeddings=32, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = load_procedural(BertModel(cfg), 3).to(DEV).train()
+    ids = torch.randint(1, 100, (2, 16), generator=torch.Generator().manual_seed(1)).to(DEV)
+    mask = torch.ones(2, 16, dtype=torch.long, device=DEV)
+    h = m(input_ids=ids, attention_mask=mask).last_hidden_state
+    h.mul_(2.0)                                   # in place, on the view of the saved arena
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        h.float().sum().backward()
+    h = m(input_ids=ids, attention_mask=mask).last_hidden_state
+    loss = h.float().sum()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
