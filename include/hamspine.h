@@ -141,6 +141,11 @@ typedef struct hs_gemm_params {
        variance for normalisation, unbiased for running_var).  colstats must then hold hs_gemm_bn_finish_rows(p) rows.  The
        caller runs hs_batchnorm_fwd with stats_done = 1 (apply pass only): one launch per BatchNorm less on the stream. */
     const struct hs_bn_params* bn_finish;
+    /* optional (with bnb_partials): the result is the gradient of relu(BatchNorm(c) + identity) -- a residual block's OUTPUT --
+       so the ReLU mask is read from the saved output bnb_y ([M][N], leading dimension ldd: mask = y > 0) instead of being
+       recomputed from c, and the launch may carry `residual` (the identity path's gradient, added BEFORE the sums are taken:
+       reference torchvision Bottleneck.forward `out += identity; out = relu(out)`).  bnb_scale / bnb_shift are then unused. */
+    const void* bnb_y;
 } hs_gemm_params;
 
 hs_status hs_gemm(const hs_gemm_params* p, void* stream);

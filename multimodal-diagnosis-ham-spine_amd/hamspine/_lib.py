@@ -55,6 +55,7 @@ class GemmParams(C.Structure):
         ("rowsum_a", vp), ("rowsum_seg", vp * 2),
         ("bnb_x", vp), ("bnb_scale", vp), ("bnb_shift", vp), ("bnb_mean", vp), ("bnb_invstd", vp), ("bnb_partials", vp),
         ("bn_finish", vp),
+        ("bnb_y", vp),
     ]
 
 

@@ -764,6 +764,7 @@ struct BnSums {
     float* partials;
     long long partials_cap;     // bytes available at `partials` (incl. the 4*C coefficient floats behind the sums)
     int* rows;
+    const void* y = nullptr;    // block-output form: dx (+ residual) is d relu(bn(c) + identity); the mask is y > 0 (hs_gemm_params.bnb_y)
 };
 static bool fused_bn_bwd_enabled() {        // HAMSPINE_FUSED_BN_BWD=0: BatchNorm backward makes its own partial-sum pass
     static int v = -1;
@@ -792,11 +793,11 @@ static int conv_dgrad_run(Run& r, const ConvShape& s, const void* dy, const void
     // with the full epilogue (the parity-ordered stride-2 walk has its own K schedule and stays whole)
     if (bnb && bnb->rows) *bnb->rows = 0;
     if (!r.plan && (knock() & 512)) return HS_OK;
-    if (bnb && !residual && r.dt == HS_BF16 && s.stride == 1 && s.Cin % 4 == 0 && fused_bn_bwd_enabled() && !(knock() & 16)) {
+    if (bnb && (!residual || bnb->y) && r.dt == HS_BF16 && s.stride == 1 && s.Cin % 8 == 0 && fused_bn_bwd_enabled() && !(knock() & 16)) {
         p.split_k = hs_gemm_suggest_split(p.M, p.N, p.K, p.dtype);             // what gemm_splitk will choose
         hs_gemm_params probe = p;
         probe.bnb_x = bnb->c; probe.bnb_scale = bnb->scale; probe.bnb_shift = bnb->shift; probe.bnb_mean = bnb->mean;
-        probe.bnb_invstd = bnb->invstd; probe.bnb_partials = bnb->partials;
+        probe.bnb_invstd = bnb->invstd; probe.bnb_partials = bnb->partials; probe.bnb_y = bnb->y;
         const int rows = r.plan ? 0 : gemm_tile_rows(&probe);
         if (rows > 0 && ((long long)rows * s.Cin * 2 + 4ll * s.Cin) * 4 <= bnb->partials_cap) {
             p = probe;
@@ -983,7 +984,16 @@ static int resblock_fwd_run(Run& r, const hs_resblock_desc& d, const void* x, vo
     return HS_OK;
 }
 
-static int resblock_bwd_run(Run& r, const hs_resblock_desc& d, const void* x, const void* y, const void* dy, void* dx) {
+// next_bn (optional): dx is the gradient of the PREVIOUS block's output relu(bn(c3) + identity); the stage-0 data-gradient GEMM
+// that writes dx also takes that BatchNorm's backward sums (block-output form of BnSums).  own (optional, own_rows > 0): this
+// block's own final BatchNorm finds its sums already there (produced by the next block's backward).
+struct OwnSums {
+    float* partials = nullptr;
+    long long bytes = 0;
+    int rows = 0;
+};
+static int resblock_bwd_run(Run& r, const hs_resblock_desc& d, const void* x, const void* y, const void* dy, void* dx,
+                            const BnSums* next_bn = nullptr, const OwnSums* own = nullptr) {
     ResLayout L;
     HS_PROPAGATE(res_layout(r, d, L));
     const int last = d.n_main - 1;
@@ -1016,7 +1026,7 @@ static int resblock_bwd_run(Run& r, const hs_resblock_desc& d, const void* x, co
     HS_PROPAGATE(side_setup(r));
 
     auto bn_backward = [&](const hs_conv_bn& cb, const StageBuf& b, long long M, const void* g_out, const void* y_out,
-                           int relu, void* g_in_, void* g_res, int partial_rows = 0) -> int {
+                           int relu, void* g_in_, void* g_res, int partial_rows = 0, const OwnSums* pre = nullptr) -> int {
         hs_bn_bwd_params q;
         memset(&q, 0, sizeof(q));
         q.partial_rows = partial_rows;
@@ -1033,12 +1043,16 @@ static int resblock_bwd_run(Run& r, const hs_resblock_desc& d, const void* x, co
         q.dgamma = cb.dgamma ? cb.dgamma : scratch_pg;
         q.dbeta = cb.dbeta ? cb.dbeta : (scratch_pg ? scratch_pg + 4096 : nullptr);
         q.ws = L.bn_ws; q.ws_bytes = L.bn_ws_bytes;
+        if (pre && pre->rows > 0) {               // the sums came with the gradient (another block's data-gradient GEMM)
+            q.partial_rows = pre->rows;
+            q.ws = pre->partials; q.ws_bytes = pre->bytes;
+        }
         CALLK(r, 16, hs_batchnorm_bwd(&q, r.s));
         return HS_OK;
     };
 
     // last main stage: y = relu(bn(c_last) + identity)
-    HS_PROPAGATE(bn_backward(d.main[last], L.main[last], Mout, dy, y, 1, g_conv[last], dres));
+    HS_PROPAGATE(bn_backward(d.main[last], L.main[last], Mout, dy, y, 1, g_conv[last], dres, 0, own));
     const void* dres_for_x = dres;   // identity shortcut: dres flows straight into dx
     if (d.has_ds) {
         // downsample branch: identity = bn(conv(x)), no ReLU
@@ -1053,7 +1067,7 @@ static int resblock_bwd_run(Run& r, const hs_resblock_desc& d, const void* x, co
         const void* in = i == 0 ? x : L.main[i - 1].a;
         if (d.main[i].dw) HS_PROPAGATE(on_side(r, [&]() { return conv_wgrad_run(r, b.s, g_conv[i], in, d.main[i].dw); }));
         if (i == 0) {
-            if (dx) HS_PROPAGATE(conv_dgrad_run(r, b.s, g_conv[i], b.w_c, dx, dres_for_x));
+            if (dx) HS_PROPAGATE(conv_dgrad_run(r, b.s, g_conv[i], b.w_c, dx, dres_for_x, next_bn));
         } else {
             // the data gradient of stage i is d relu(bn(c)) of stage i - 1: its GEMM takes that BatchNorm's backward sums along
             const StageBuf& pb = L.main[i - 1];
@@ -1605,6 +1619,19 @@ static int resnet_bwd_run(Run& r, const hs_resnet_desc& d, const void* const* dy
         r.grp_conv = gemm_group_open(r.s, 1);
         HS_REQUIRE(r.grp_pw && r.grp_conv, "resnet_bwd: cannot set up the grouped weight-gradient launches");
     }
+    // Block-final BatchNorm sums across the block boundary: block i + 1's stage-0 data-gradient GEMM writes the gradient of
+    // block i's output, so it also takes the sums of block i's last BatchNorm (two buffers, alternating; HAMSPINE_FUSED_BN_BWD=0
+    // or an intermediate tap whose gradient joins afterwards switch it off for that block).
+    long long xs_bytes = 0;
+    for (int i = 0; i < d.n_blocks; ++i) {
+        int C, H, W;
+        const long long ob = out_bytes_of(d.blocks[i], dt, &C, &H, &W);
+        const long long rows = (ob / esize(dt) / C + 63) / 64;
+        xs_bytes = std::max<long long>(xs_bytes, (rows * C * 2 + 4ll * C) * 4);
+    }
+    float* xs_buf[2] = {(float*)r.ws.alloc(xs_bytes), (float*)r.ws.alloc(xs_bytes)};
+    OwnSums own_next;                 // sums of the block about to be processed, if the previous iteration produced them
+    int xs_rows = 0;
     for (int i = d.n_blocks - 1; i >= 0; --i) {
         const bool is_tap = tap >= 0 && d.tap_block[tap] == i;
         const void* ext = is_tap && dy_taps ? dy_taps[tap] : nullptr;
@@ -1619,9 +1646,33 @@ static int resnet_bwd_run(Run& r, const hs_resnet_desc& d, const void* const* dy
         const char* x = r.saved.base ? r.saved.base + lo.y_off[i] : nullptr;
         const char* y = r.saved.base ? r.saved.base + lo.y_off[i + 1] : nullptr;
         char* dx = gbuf[cur ^ 1];
+        // sums for block i - 1's final BatchNorm ride on this block's stage-0 data gradient when that gradient IS the whole
+        // gradient of block i - 1's output (no tap gradient joins it later) and block i - 1 is a three-stage block
+        BnSums next_bn;
+        const BnSums* nb = nullptr;
+        const bool prev_tap = i > 0 && tap >= 0 && d.tap_block[tap] == i - 1 && dy_taps && dy_taps[tap];
+        // MEASURED (round 3, rocprofv3, un-overlapped C2 step): the rider's epilogue reads three more tensors (c3, y, identity
+        // gradient) per fragment; the 64x64-tile launches take 33 us against 14 + 21 us for GEMM + bn_bwd_partial (a wash), the
+        // 128x64-tile ones 73 us against 30 + 21 (worse): kernel time 14.33 vs 14.15 ms per step.  OFF unless HAMSPINE_XBLOCK_BN=1.
+        static const bool xblock = [] { const char* e = getenv("HAMSPINE_XBLOCK_BN"); return e && e[0] == '1'; }();
+        if (xblock && i > 0 && dt == HS_BF16 && !prev_tap && !r.plan && d.blocks[i].main[0].stride == 1 && fused_bn_bwd_enabled()) {
+            const hs_resblock_desc& pb = d.blocks[i - 1];
+            const long long keep_saved = r.saved.off, keep_ws = r.ws.mark();
+            r.saved.off = lo.lay_off[i];
+            ResLayout PL;
+            HS_PROPAGATE(res_layout(r, pb, PL));
+            const StageBuf& lb = PL.main[pb.n_main - 1];
+            r.saved.off = keep_saved;
+            r.ws.release(keep_ws);
+            xs_rows = 0;
+            next_bn = BnSums{lb.c, lb.scale, lb.shift, lb.mean, lb.invstd, xs_buf[i & 1], xs_bytes, &xs_rows, x};
+            nb = &next_bn;
+        }
         r.saved.off = lo.lay_off[i + 1];
         const long long wm = r.ws.mark();
-        HS_PROPAGATE(resblock_bwd_run(r, d.blocks[i], x, y, dy, dx));
+        HS_PROPAGATE(resblock_bwd_run(r, d.blocks[i], x, y, dy, dx, nb, own_next.rows > 0 ? &own_next : nullptr));
+        own_next = OwnSums{};
+        if (nb && xs_rows > 0) own_next = OwnSums{xs_buf[i & 1], xs_bytes, xs_rows};
         if (!r.defer_wgrad) r.ws.release(wm);
         dy = dx;
         cur ^= 1;

@@ -208,14 +208,17 @@ static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q
     a.accumulate = p->accumulate;
     a.colstats = p->colstats;
     if (p->bnb_partials) {
-        HS_REQUIRE(bf16 && p->out_dtype == HS_BF16 && batch == 1 && (combo == 1 || combo == 4) && p->bnb_x && p->bnb_scale && p->bnb_shift &&
-                       p->bnb_mean && p->bnb_invstd && !p->bias && !p->colscale && p->act == HS_ACT_NONE && !p->residual && !p->D_preact &&
+        HS_REQUIRE(bf16 && p->out_dtype == HS_BF16 && batch == 1 && (combo == 1 || combo == 4) && p->bnb_x && ((p->bnb_scale && p->bnb_shift) || p->bnb_y) &&
+                       p->bnb_mean && p->bnb_invstd && !p->bias && !p->colscale && p->act == HS_ACT_NONE && (!p->residual || (p->bnb_y && p->ldr == p->ldd)) && !p->D_preact &&
                        p->mul_mode == HS_MUL_NONE && p->dropout_p == 0.f && !p->accumulate && p->seg_rows <= 0 && p->alpha == 1.f &&
                        p->N % 4 == 0 && p->ldd % 4 == 0 && ((((uintptr_t)p->bnb_x) & 7) == 0),
                    "hs_gemm: bnb_partials needs a bf16 data-gradient GEMM with a plain epilogue (no bias / activation / residual / multiplier)");
         a.bnb_x = (const char*)p->bnb_x;
         a.bnb_scale = p->bnb_scale; a.bnb_shift = p->bnb_shift; a.bnb_mean = p->bnb_mean; a.bnb_invstd = p->bnb_invstd;
         a.bnb_partials = p->bnb_partials;
+        a.bnb_y = (const char*)p->bnb_y;
+        HS_REQUIRE(!p->bnb_y || ((((uintptr_t)p->bnb_y) & 7) == 0 && (!p->residual || (((uintptr_t)p->residual) & 7) == 0)),
+                   "hs_gemm: bnb_y / residual must be 8-byte aligned");
     }
     a.colscale = p->colscale;
     a.res_pre_act = p->residual_before_act;

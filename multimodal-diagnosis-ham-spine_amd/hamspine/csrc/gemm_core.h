@@ -72,6 +72,7 @@ struct GemmArgs {
     const char* bnb_x;
     const float *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd;
     float* bnb_partials;
+    const char* bnb_y;         // optional: the mask comes from this saved block output (y > 0) and a.residual is added before the sums
     // optional (BNF kernels, with colstats): the launch also FINISHES the following BatchNorm's statistics -- the last workgroup
     // of a column tile merges the row tiles' partials and writes mean / invstd / scale / shift (+ running statistics); see
     // hs_gemm_params.bn_finish.  bnf_tickets: tiles_n * (1 + stat_groups(tiles_m)) zeroed arrival counters.
@@ -1180,8 +1181,13 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
         }
     }
     // ---- optional: BatchNorm-backward sums of this tile (the result is d relu(bn(c)); plain epilogue, alpha = 1) -----------
+    // Block-output form (a.bnb_y): the result + a.residual is the gradient of relu(bn(c) + identity); the residual is added
+    // HERE (the epilogue below then runs without it) and the mask is y > 0 on the saved block output.
+    bool res_consumed = false;
     if constexpr (BNS) {
         if (a.bnb_partials) {
+            const bool from_y = a.bnb_y != nullptr;
+            res_consumed = from_y && a.residual != nullptr;
             float s1[FN][4], s2[FN][4];
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
@@ -1189,8 +1195,10 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
                 const bool nok = n < argN;
                 f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc, mu = sc, is = sc;
                 if (nok) {
-                    sc = *(const HS_GLOBAL f32x4*)(a.bnb_scale + n);
-                    sh = *(const HS_GLOBAL f32x4*)(a.bnb_shift + n);
+                    if (!from_y) {
+                        sc = *(const HS_GLOBAL f32x4*)(a.bnb_scale + n);
+                        sh = *(const HS_GLOBAL f32x4*)(a.bnb_shift + n);
+                    }
                     mu = *(const HS_GLOBAL f32x4*)(a.bnb_mean + n);
                     is = *(const HS_GLOBAL f32x4*)(a.bnb_invstd + n);
                 }
@@ -1198,13 +1206,23 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     const int m = m0 + wm * WM + i * 16 + l15;
-                    float cv[4] = {0.f, 0.f, 0.f, 0.f};
+                    float cv[4] = {0.f, 0.f, 0.f, 0.f}, yv[4] = {0.f, 0.f, 0.f, 0.f};
                     const bool live = nok && m < argM;
                     if (live) load4<T>(a.bnb_x, (long long)m * a.ldd + n, true, 4, cv);
+                    if (from_y && live) {
+                        load4<T>(a.bnb_y, (long long)m * a.ldd + n, true, 4, yv);
+                        if (res_consumed) {
+                            float rv[4];
+                            load4<T>(a.residual, (long long)m * a.ldr + n, true, 4, rv);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i][j][e] += rv[e];
+                        }
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float gq = (float)(bf16_t)acc[i][j][e];                      // the value the epilogue stores
-                        const float dz = (live && fmaf(cv[e], sc[e], sh[e]) > 0.f) ? gq : 0.f;
+                        const bool on = from_y ? yv[e] > 0.f : fmaf(cv[e], sc[e], sh[e]) > 0.f;
+                        const float dz = (live && on) ? gq : 0.f;
                         u[e] += dz;
                         w[e] = fmaf(dz, (cv[e] - mu[e]) * is[e], w[e]);
                     }
@@ -1259,14 +1277,15 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
     }
     // whole tile inside the matrix and 4-wide storable: one of the feature sets the training / inference steps use gets
     // branch-free code; anything else (edge tiles, rare combinations) takes the generic body
+    const unsigned epi_e = res_consumed ? (epi & ~(unsigned)EPI_RES_POST) : epi;     // (the sums' rider already added the residual)
     const bool full = !a.epi_generic && (epi & EPI_VEC) && em0 + BM <= argM && en0 + BN <= argN;
     bool done = false;
     const int ze = split_k > 1 ? 0 : z;                       // batch index seen by the epilogue (a split-K launch has no batch)
     if (full) {
         done = true;
-#define HS_EPI_CASE(F) case (F): run_epilogue<T, (F), true, FM, FN, WM, WN>(a, epi, acc, em0, en0, wm, wn, l15, g, d_boff, ze); break
-        const bool v16 = epi & EPI_VEC16;
-        const unsigned key = epi & ~EPI_VEC16;
+#define HS_EPI_CASE(F) case (F): run_epilogue<T, (F), true, FM, FN, WM, WN>(a, epi_e, acc, em0, en0, wm, wn, l15, g, d_boff, ze); break
+        const bool v16 = epi_e & EPI_VEC16;
+        const unsigned key = epi_e & ~EPI_VEC16;
         if (!v16 && !(key & EPI_OUT_F32)) done = false;      // bf16 rows that cannot take 16-byte stores: generic body
         else switch (key) {
             HS_EPI_CASE(EPI_VEC);                                                     // plain bf16 result
@@ -1286,7 +1305,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
         }
 #undef HS_EPI_CASE
     }
-    if (!done) run_epilogue<T, -1, false, FM, FN, WM, WN>(a, epi, acc, em0, en0, wm, wn, l15, g, d_boff, ze);
+    if (!done) run_epilogue<T, -1, false, FM, FN, WM, WN>(a, epi_e, acc, em0, en0, wm, wn, l15, g, d_boff, ze);
     HS_STAMP(4);
     if constexpr (BNF && !PS) {
         if (a.bnf_tickets) {

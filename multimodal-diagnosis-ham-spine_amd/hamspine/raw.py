@@ -96,9 +96,12 @@ def gemm(A, B, D, M, N, K, a_kind=L.A_KC, b_kind=L.B_KC, lda=0, ldb=0, ldd=None,
     p.rowsum_a = ptr(rowsum_a)
     partials = None
     if bnb is not None:
-        c, sc, sh, mu, inv = bnb
+        c, sc, sh, mu, inv = bnb[:5]
         need_gpu(c, sc, sh, mu, inv)
         p.bnb_x, p.bnb_scale, p.bnb_shift, p.bnb_mean, p.bnb_invstd = ptr(c), ptr(sc), ptr(sh), ptr(mu), ptr(inv)
+        if len(bnb) > 5:                 # block-output form: mask from the saved output y (hs_gemm_params.bnb_y)
+            need_gpu(bnb[5])
+            p.bnb_y = ptr(bnb[5])
         p.bnb_partials = 16              # any non-null value: hs_gemm_tile_rows only looks at the configuration
         rows = int(L.lib().hs_gemm_tile_rows(C.byref(p)))
         if rows <= 0:

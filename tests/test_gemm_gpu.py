@@ -357,6 +357,37 @@ def test_data_gradient_gemm_takes_the_batchnorm_backward_sums(M, N, K, split):
     assert ((s[:, 1] - want2).abs() <= tol2).all()
 
 
+@pytest.mark.parametrize("M,N,K,with_res", [(6272, 1024, 256, True), (100352, 256, 64, True), (1000, 72 + 8, 320, True), (25088, 512, 128, False)])
+def test_data_gradient_gemm_takes_the_block_final_batchnorm_sums(M, N, K, with_res):
+    """block-output form of the rider (hs_gemm_params.bnb_y): dx = dy W + identity-path gradient is the gradient of
+    relu(bn(c) + identity); the mask is y > 0 on the saved block output, the residual is added before the sums and before
+    the (single) bf16 rounding of the stored result"""
+    g = torch.Generator().manual_seed(M + N + 3)
+    BF = torch.bfloat16
+    dy = (torch.randn(M, K, generator=g) * 0.5).to(BF).to(DEV)
+    W = (torch.randn(K, N, generator=g) * 0.1).to(BF).to(DEV)
+    c = torch.randn(M, N, generator=g).to(BF).to(DEV)
+    y = torch.relu(torch.randn(M, N, generator=g)).to(BF).to(DEV)
+    res = (torch.randn(M, N, generator=g) * 0.3).to(BF).to(DEV) if with_res else None
+    mean, invstd = torch.randn(N, generator=g) * 0.2, torch.rand(N, generator=g) + 0.5
+    dev = lambda t: t.float().to(DEV)
+    D = torch.full((M, N), float("nan"), dtype=BF, device=DEV)
+    D, part = raw.gemm(dy, W, D, M, N, K, a_kind=L.A_KC, b_kind=L.B_RC, lda=K, ldb=N, residual=res,
+                       bnb=(c, dev(mean), dev(mean), dev(mean), dev(invstd), y))
+    ref = dy.float() @ W.float() + (res.float() if with_res else 0.0)
+    assert (D.float() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item() + 1e-6
+    # without the rider the same launch stores the same values (the residual is added exactly once either way)
+    D0 = torch.full((M, N), float("nan"), dtype=BF, device=DEV)
+    raw.gemm(dy, W, D0, M, N, K, a_kind=L.A_KC, b_kind=L.B_RC, lda=K, ldb=N, residual=res)
+    assert torch.equal(D0, D)
+    dd, cd = D.double().cpu(), c.double().cpu()
+    dz = dd * (y.double().cpu() > 0)
+    xhat = (cd - mean.float().double()) * invstd.float().double()
+    s = part.double().cpu().sum(0)
+    assert ((s[:, 0] - dz.sum(0)).abs() <= 1e-4 * dz.abs().sum(0) + 1e-6).all()
+    assert ((s[:, 1] - (dz * xhat).sum(0)).abs() <= 1e-4 * (dz * xhat).abs().sum(0) + 1e-6).all()
+
+
 @pytest.mark.parametrize("case", [
     # (M, N, K) of 1x1 convolutions (K-contiguous operands): one merge level, two levels (ragged last group), ragged tiles
     ("pw", 1568, 2048, 512), ("pw", 100352, 64, 64), ("pw", 25088, 512, 128), ("pw", 1000, 72, 320), ("pw", 6272 + 40, 256, 1024),
