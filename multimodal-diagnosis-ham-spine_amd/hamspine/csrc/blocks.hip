@@ -1631,6 +1631,8 @@ static int resnet_bwd_run(Run& r, const hs_resnet_desc& d, const void* const* dy
     }
     float* xs_buf[2] = {(float*)r.ws.alloc(xs_bytes), (float*)r.ws.alloc(xs_bytes)};
     OwnSums own_next;                 // sums of the block about to be processed, if the previous iteration produced them
+    const char* xb_env = getenv("HAMSPINE_XBLOCK_BN");       // read per call: tests compare both settings in one process
+    const int xblock = xb_env ? atoi(xb_env) : 1;
     int xs_rows = 0;
     for (int i = d.n_blocks - 1; i >= 0; --i) {
         const bool is_tap = tap >= 0 && d.tap_block[tap] == i;
@@ -1651,11 +1653,13 @@ static int resnet_bwd_run(Run& r, const hs_resnet_desc& d, const void* const* dy
         BnSums next_bn;
         const BnSums* nb = nullptr;
         const bool prev_tap = i > 0 && tap >= 0 && d.tap_block[tap] == i - 1 && dy_taps && dy_taps[tap];
-        // MEASURED (round 3, rocprofv3, un-overlapped C2 step): the rider's epilogue reads three more tensors (c3, y, identity
-        // gradient) per fragment; the 64x64-tile launches take 33 us against 14 + 21 us for GEMM + bn_bwd_partial (a wash), the
-        // 128x64-tile ones 73 us against 30 + 21 (worse): kernel time 14.33 vs 14.15 ms per step.  OFF unless HAMSPINE_XBLOCK_BN=1.
-        static const bool xblock = [] { const char* e = getenv("HAMSPINE_XBLOCK_BN"); return e && e[0] == '1'; }();
-        if (xblock && i > 0 && dt == HS_BF16 && !prev_tap && !r.plan && d.blocks[i].main[0].stride == 1 && fused_bn_bwd_enabled()) {
+        // MEASURED (round 3, rocprofv3, un-overlapped C2 step, rider operands fetched in front of the K walk): the rider reads
+        // three more tensors (c3, y, identity gradient).  Where the block input is small (64x64-tile launches, M <= 6272 at
+        // C2) the launch takes 29 us against 18 + 23 us for GEMM + bn_bwd_partial; on the big early layers (128x64 tiles,
+        // M >= 25088) it is bandwidth-bound inside a tiled GEMM (205 MB at 3.4 TB/s: 61 us against 30 + 23) -> size gate.
+        // HAMSPINE_XBLOCK_BN=0 turns it off, =2 takes it on every eligible block.
+        const bool xb_size = xblock >= 2 || lo.y_bytes[i] <= (16ll << 20);
+        if (xblock > 0 && xb_size && i > 0 && dt == HS_BF16 && !prev_tap && !r.plan && d.blocks[i].main[0].stride == 1 && fused_bn_bwd_enabled()) {
             const hs_resblock_desc& pb = d.blocks[i - 1];
             const long long keep_saved = r.saved.off, keep_ws = r.ws.mark();
             r.saved.off = lo.lay_off[i];

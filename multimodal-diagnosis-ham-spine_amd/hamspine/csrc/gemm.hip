@@ -132,9 +132,40 @@ static int auto_cfg(const hs_gemm_params* p, bool vec) {
     }
     return (vec && t128 >= 200) ? CFG_128x128 : CFG_64x64;
 }
+// The 3x3 halo-patch kernel (conv3.hip) takes stride-1 pad-1 3x3 forward convolutions in standard NHWC with a plain bf16
+// epilogue (optionally the BatchNorm statistics riders): tile = R whole image rows (R * W <= 112 pixels) x 64 channels.
+// HAMSPINE_CONV3=0 keeps them on the generic implicit GEMM.
+static bool conv3_enabled() {
+    static const bool on = [] { const char* e = getenv("HAMSPINE_CONV3"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static bool conv3_plan(const hs_gemm_params* p, int* rows, int* tpi, int* fm) {
+    if (!conv3_enabled() || g_dbg_cfg >= 0) return false;
+    const hs_conv_geom& g = p->g;
+    if (p->dtype != HS_BF16 || p->a_kind != HS_A_CONV || p->b_kind != HS_B_KC || p->split_k > 1 || p->batch > 1) return false;
+    if (g.R != 3 || g.S != 3 || g.stride != 1 || g.pad != 1 || g.P != g.H || g.Q != g.W || g.C % 64 != 0 || p->N % 64 != 0) return false;
+    if (g.row_pitch != g.W * g.C || g.img_pitch != g.H * g.W * g.C || g.qstep != g.C || g.no_bounds) return false;
+    if (p->bias || p->colscale || p->act != HS_ACT_NONE || p->residual || p->D_preact || p->mul_mode != HS_MUL_NONE || p->dropout_p > 0.f ||
+        p->accumulate || p->seg_rows > 0 || p->alpha != 1.f || p->out_dtype != HS_BF16 || p->rowsum_a || p->bnb_partials)
+        return false;
+    if (p->ldd % 8 != 0 || (((uintptr_t)p->D) & 15) != 0 || p->ldb != 9 * g.C || p->K != 9 * g.C || p->N != g.K) return false;
+    if (g.W > 112 || g.W < 1) return false;
+    const int rmax = std::min(g.H, 112 / g.W);
+    const int t = ceil_div(g.H, rmax), r = ceil_div(g.H, t);
+    const int tp = r * g.W;
+    if (tp < 32 || (r + 2) * (g.W + 2) > 256) return false;
+    *rows = r;
+    *tpi = t;
+    *fm = tp > 64 ? 7 : 4;
+    return true;
+}
 // rows of a colstats buffer = row tiles the bf16 kernel will use for p
 int gemm_stat_rows(const hs_gemm_params* p) {
     if (!p || p->dtype != HS_BF16 || p->split_k > 1 || p->batch > 1) return 0;
+    {
+        int r, t, fm;
+        if (conv3_plan(p, &r, &t, &fm)) return p->g.N * t;
+    }
     int cfg = (p->a_kind == HS_A_CONV && p->b_kind == HS_B_KC && p->g.C % 64 != 0) ? CFG_STEM : auto_cfg(p, true);
     if (g_dbg_cfg >= 0 && g_dbg_cfg <= CFG_64x64 && cfg != CFG_STEM) cfg = g_dbg_cfg;
     if (g_dbg_cfg >= CFG_256x128 && g_dbg_cfg <= CFG_256x128x32 && !(p->a_kind == HS_A_CONV || p->a_kind == HS_A_DGRAD || p->b_kind == HS_B_CONV)) cfg = g_dbg_cfg;
@@ -143,7 +174,7 @@ int gemm_stat_rows(const hs_gemm_params* p) {
 
 // tiles / layouts with a BatchNorm-finishing kernel variant (gemm_bf16_bnf_kernel): forward convolutions and 1x1 convolutions
 static bool bn_finish_variant(int cfg, int combo) {
-    return (combo == 0 && (cfg == CFG_64x64 || cfg == CFG_128x64)) || (combo == 3 && (cfg == CFG_64x64 || cfg == CFG_128x64 || cfg == CFG_STEM));
+    return (combo == 0 && (cfg == CFG_64x64 || cfg == CFG_128x64)) || (combo == 3 && (cfg == CFG_64x64 || cfg == CFG_128x64 || cfg == CFG_STEM || cfg == CFG_C3));
 }
 
 // everything gemm_impl decides before the launch
@@ -349,6 +380,7 @@ static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q
         else if (g_dbg_cfg < 0 && p8_enabled()) want = p8_cfg(p);
         if (p8_ok && want >= 0 && fits(want)) cfg = want;
     }
+    if (force_cfg < 0 && combo == 3 && conv3_plan(p, &a.c3_rows, &a.c3_tpi, &a.c3_fm)) cfg = CFG_C3;
     // (A deeper operand ring -- 5 / 8 slots for the long-K split weight gradients of the convolutions -- was built and
     // measured: 1.93 vs 1.92 ms per step on the 1x1 weight gradients, 0.70 vs 0.52 ms on the 3x3 ones, where the larger LDS
     // footprint costs a resident workgroup.  The kernel keeps the ring depth as a template parameter; 3 is what runs.)
@@ -362,6 +394,12 @@ static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q
     else if (cfg == CFG_128x64 || cfg == CFG_STEM) { BM = 128; BN = 64; }
     a.tiles_m = ceil_div(p->M, BM);
     a.tiles_n = ceil_div(p->N, BN);
+    if (cfg == CFG_C3) {
+        a.tiles_m = p->g.N * a.c3_tpi;
+        a.tiles_n = p->N / 64;
+        a.div_mw = make_fastdiv(p->g.W);
+        a.div_qw = make_fastdiv(p->g.W + 2);
+    }
     const int kb_cfg = (cfg == CFG_STEM || cfg == CFG_128x128x32 || cfg == CFG_256x128x32) ? 32 : bk;
     {
         // K tiles one workgroup walks -> LDS ring slots it needs (a single-tile 1x1 convolution allocates one slot, so
@@ -510,7 +548,8 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
     int st;
     ProfRec rec;
     const bool timed = prof_begin(stream, q.flops, (bf16 ? 0 : 2) + (conv ? 1 : 0), rec);
-    if (bf16 && cfg >= CFG_P8_256 && cfg <= CFG_P8_128) st = launch_bf16_p8(cfg, a, grid, stream);
+    if (bf16 && cfg == CFG_C3) st = launch_bf16_conv3(a, a.c3_fm, grid, stream);
+    else if (bf16 && cfg >= CFG_P8_256 && cfg <= CFG_P8_128) st = launch_bf16_p8(cfg, a, grid, stream);
     else if (bf16) st = conv ? launch_bf16_conv(cfg, combo, a, grid, stream) : launch_bf16_plain(cfg, combo, a, grid, stream);
     else st = conv ? launch_f32_conv(cfg, combo, a, grid, stream) : launch_f32_plain(cfg, combo, vec, a, grid, stream);
     if (timed) {

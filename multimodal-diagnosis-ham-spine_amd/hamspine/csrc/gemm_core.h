@@ -81,6 +81,7 @@ struct GemmArgs {
     float bnf_eps, bnf_momentum;
     unsigned* bnf_tickets;
     float* rowsum[3];          // optional (row-contiguous A): rowsum[seg][m] = sum_k A[k][m], the bias gradient of a wgrad GEMM
+    int c3_rows, c3_tpi, c3_fm;   // 3x3 halo kernel (conv3.hip): image rows per tile, tiles per image, 16-row fragments per tile
     int vec16;                    // bf16 result rows allow 16-byte (8-column) stores: N, ldd, batch strides % 8 == 0, bases 16-byte aligned
     int epi_generic;              // measurement only (hs_gemm_debug bit 32): always take the generic epilogue body
     int dbg;                      // measurement only: the hs_gemm_debug ablation bits
@@ -625,6 +626,129 @@ __device__ __forceinline__ void wait_vm_tiles(int tiles) {       // wait until a
         default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * NDMA) : "memory"); break;
     }
 }
+// ---- BatchNorm statistics hand-off of a forward convolution (BNF kernels; also the 3x3 halo kernel, conv3.hip) ------------
+// Called by every thread of the workgroup after its (count, mean, M2) partial row of tile row tm has been stored
+// write-through and its arrival ticket drawn (bnf_drawn, held by thread 0).  NT threads, BN columns per tile, smem: at
+// least (NT * 3 + 1) floats that nobody else uses any more.
+template <int NT, int BN>
+__device__ __forceinline__ void bnf_handoff(const GemmArgs& a, char* smem, const int tid, const int tm, const int tn, const int en0,
+                                            int bnf_drawn) {
+    // The statistics of the following BatchNorm are finished inside the launch (the separate bn_stats_final_kernel sat on
+    // the ResNet stream's critical path 53 times a step: ~7 us each + a dispatch gap, for microseconds of arithmetic).
+    // Same hand-off as the split-K reduction above: write-through partials -> vmcnt(0) -> barrier -> one relaxed
+    // agent-scope ticket; the workgroup that arrives last acquires and merges.  Two levels so that the tail stays
+    // short: the row tiles of a column tile hand off in groups of kStatGroup (the last of a group merges it into one
+    // (count, mean, M2) row behind the tile rows), then the last group merges the group rows and writes the
+    // statistics.  Merging is the grouped formula (n = sum n_i, mean = sum n_i mean_i / n,
+    // M2 = sum M2_i + n_i (mean_i - mean)^2, evaluated about a shift) in a fixed order: deterministic whichever tile
+    // arrives last.
+    constexpr int TPC = NT / BN, UB = 8;
+    static_assert(NT % BN == 0 && TPC >= 1, "threads per column");
+    float* sh = (float*)smem;                                  // [TPC][BN][3]; the ring is free
+    int* flag = (int*)(sh + NT * 3);
+    const int tiles_m = a.tiles_m, ngroups = stat_groups(tiles_m);
+    const int col = tid % BN, sub = tid / BN, n = en0 + col;
+    const bool cok = n < a.N;
+    const int grp = tm / kStatGroup;
+    int first = ngroups ? grp * kStatGroup : 0, count = ngroups ? min(kStatGroup, tiles_m - first) : tiles_m;
+    unsigned* ticket = ngroups ? a.bnf_tickets + a.tiles_n + tn * ngroups + grp : a.bnf_tickets + tn;
+    const unsigned st_bytes = (unsigned)min((unsigned long long)(tiles_m + ngroups) * a.N * 12ull, 0x7fffff00ull);
+    const __amdgpu_buffer_rsrc_t rsS = make_rsrc(a.colstats, st_bytes);
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+    bool early = true;                                         // the first hand-off's ticket was drawn before the epilogue
+#pragma unroll 1
+    for (int level = ngroups ? 0 : 1; level < 2; ++level) {
+        if (!early) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the group row's stores have left
+            __syncthreads();
+            if (tid == 0) bnf_drawn = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        early = false;
+        if (tid == 0) *flag = bnf_drawn;
+        __syncthreads();
+        const int drawn = *flag;
+        __syncthreads();
+        if (drawn != count - 1) return;                        // (workgroup-uniform)
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the next launch
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // one pass, every load of a batch in flight together (dependent passes cost a memory round trip each on the
+        // launch's tail).  Each thread sums n_i, n_i d_i and M2_i + n_i d_i^2 of its rows with d_i = mean_i - k, k = the
+        // mean of the thread's FIRST row (any row's mean is within a tile's standard error of the answer, so the final
+        // S2 - S1^2 / S0 cancels nothing; the first row rather than this workgroup's own tile so that the rounding does
+        // not depend on which tile arrived last); the TPC threads of a column then merge their triples the same way.
+        float k = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int r0 = sub; r0 < count; r0 += TPC * UB) {
+            float v[UB][3];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int r = r0 + u * TPC;
+                const unsigned off = (cok && r < count) ? (unsigned)(((long long)(first + r) * a.N + n) * 12) : kOOB;
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+                    v[u][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsS, off + 4 * e, 0, 16 /* sc1: written by other XCDs */));
+            }
+            if (r0 == sub) k = v[0][1];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {                      // rows past the range read as zeros: no contribution
+                const float c = v[u][0], d = v[u][1] - k;
+                s0 += c;
+                s1 = fmaf(c, d, s1);
+                s2 += fmaf(c * d, d, v[u][2]);
+            }
+        }
+        {
+            const float dm = s0 > 0.f ? s1 / s0 : 0.f;
+            sh[(sub * BN + col) * 3] = s0;
+            sh[(sub * BN + col) * 3 + 1] = k + dm;
+            sh[(sub * BN + col) * 3 + 2] = fmaxf(s2 - s1 * dm, 0.f);
+        }
+        __syncthreads();
+        k = sh[col * 3 + 1];                                   // thread 0 of the column always has a row
+        s0 = 0.f; s1 = 0.f; s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < TPC; ++u) {
+            const float c = sh[(u * BN + col) * 3], d = sh[(u * BN + col) * 3 + 1] - k;
+            s0 += c;
+            s1 = fmaf(c, d, s1);
+            s2 += fmaf(c * d, d, sh[(u * BN + col) * 3 + 2]);
+        }
+        __syncthreads();
+        cnt = s0;
+        const float dm = s0 > 0.f ? s1 / s0 : 0.f;
+        mean = k + dm;
+        m2 = fmaxf(s2 - s1 * dm, 0.f);
+        if (level == 0) {
+            if (sub == 0 && cok) {
+                float* o = a.colstats + ((long long)(tiles_m + grp) * a.N + n) * 3;
+                __hip_atomic_store(o, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(o + 1, mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(o + 2, m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            first = tiles_m;
+            count = ngroups;
+            ticket = a.bnf_tickets + tn;
+        }
+    }
+    if (sub == 0 && cok) {                                     // the launch's last workgroup of this column tile
+        const float rows = (float)a.M;
+        const float var = m2 / rows;                           // biased, used for normalisation
+        const float invstd = rsqrtf(var + a.bnf_eps);
+        a.bnf_mean[n] = mean;
+        a.bnf_invstd[n] = invstd;
+        const float gm = a.bnf_gamma ? a.bnf_gamma[n] : 1.f, bt = a.bnf_beta ? a.bnf_beta[n] : 0.f;
+        a.bnf_scale[n] = gm * invstd;
+        a.bnf_shift[n] = bt - mean * gm * invstd;
+        if (a.bnf_rmean) {
+            const float unbiased = a.M > 1 ? m2 / (rows - 1.f) : var;
+            a.bnf_rmean[n] = (1.f - a.bnf_momentum) * a.bnf_rmean[n] + a.bnf_momentum * mean;
+            a.bnf_rvar[n] = (1.f - a.bnf_momentum) * a.bnf_rvar[n] + a.bnf_momentum * unbiased;
+        }
+    }
+}
 // SK: the launch may be a split-K one (false: the slab / hand-off code is left out -- its registers count against every launch).
 // PS: persistent-capable (the tile loop and the next-tile prefetch are compiled in; costs registers, so it is a variant).
 // BNS: the epilogue can also take the BatchNorm-backward sums of the result (a.bnb_partials; data gradients of ResNet blocks).
@@ -873,6 +997,33 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
                 if (q < ntiles) stage_dma(q, k_of(q));
         }
     };
+    // BNS: the rider's operands (the BatchNorm input c; the saved block output and the skip gradient in the block-output
+    // form) do not depend on this GEMM: fetched HERE, in front of the K walk (they are the oldest entries of the memory
+    // pipe, so the first counted wait covers them), they cost 8 registers per operand on a 64x64 tile instead of one
+    // exposed round trip per fragment behind the last MFMA.  Split-K launches keep the loads in the rider: only the
+    // workgroup that finishes a tile runs it.
+    constexpr int PFM = BNS ? FM : 1, PFN = BNS ? FN : 1;
+    u32x2 pf_c[PFM][PFN], pf_y[PFM][PFN], pf_r[PFM][PFN];
+    bool pf = false;
+    if constexpr (BNS) {
+        if (a.bnb_partials && a.split_k == 1) {
+            pf = true;
+            const bool wy = a.bnb_y != nullptr, wr = wy && a.residual != nullptr;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int m = m0 + wm * WM + i * 16 + l15, n = n0 + wn * WN + j * 16 + 4 * g;
+                    const bool live = m < a.M && n < a.N;
+                    pf_c[i][j] = pf_y[i][j] = pf_r[i][j] = u32x2{0u, 0u};
+                    if (live) {
+                        pf_c[i][j] = *(const HS_GLOBAL u32x2*)((const HS_GLOBAL T*)a.bnb_x + (long long)m * a.ldd + n);
+                        if (wy) pf_y[i][j] = *(const HS_GLOBAL u32x2*)((const HS_GLOBAL T*)a.bnb_y + (long long)m * a.ldd + n);
+                        if (wr) pf_r[i][j] = *(const HS_GLOBAL u32x2*)((const HS_GLOBAL T*)a.residual + (long long)m * a.ldr + n);
+                    }
+                }
+        }
+    }
     issue_prologue();
     HS_STAMP(1);
     if (a.stamps && threadIdx.x == 0) a.stamps[((long long)blockIdx.z * gridDim.x + blockIdx.x) * 6] = t_entry;
@@ -1208,6 +1359,24 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
                     const int m = m0 + wm * WM + i * 16 + l15;
                     float cv[4] = {0.f, 0.f, 0.f, 0.f}, yv[4] = {0.f, 0.f, 0.f, 0.f};
                     const bool live = nok && m < argM;
+                    auto unpack = [](const u32x2 v, float* f) {
+                        f[0] = __uint_as_float(v[0] << 16);
+                        f[1] = __uint_as_float(v[0] & 0xffff0000u);
+                        f[2] = __uint_as_float(v[1] << 16);
+                        f[3] = __uint_as_float(v[1] & 0xffff0000u);
+                    };
+                    if (pf) {
+                        unpack(pf_c[i][j], cv);
+                        if (from_y) {
+                            unpack(pf_y[i][j], yv);
+                            if (res_consumed) {
+                                float rv[4];
+                                unpack(pf_r[i][j], rv);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[i][j][e] += rv[e];
+                            }
+                        }
+                    } else {
                     if (live) load4<T>(a.bnb_x, (long long)m * a.ldd + n, true, 4, cv);
                     if (from_y && live) {
                         load4<T>(a.bnb_y, (long long)m * a.ldd + n, true, 4, yv);
@@ -1217,6 +1386,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
 #pragma unroll
                             for (int e = 0; e < 4; ++e) acc[i][j][e] += rv[e];
                         }
+                    }
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -1308,123 +1478,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
     if (!done) run_epilogue<T, -1, false, FM, FN, WM, WN>(a, epi_e, acc, em0, en0, wm, wn, l15, g, d_boff, ze);
     HS_STAMP(4);
     if constexpr (BNF && !PS) {
-        if (a.bnf_tickets) {
-            // The statistics of the following BatchNorm are finished inside the launch (the separate bn_stats_final_kernel sat on
-            // the ResNet stream's critical path 53 times a step: ~7 us each + a dispatch gap, for microseconds of arithmetic).
-            // Same hand-off as the split-K reduction above: write-through partials -> vmcnt(0) -> barrier -> one relaxed
-            // agent-scope ticket; the workgroup that arrives last acquires and merges.  Two levels so that the tail stays
-            // short: the row tiles of a column tile hand off in groups of kStatGroup (the last of a group merges it into one
-            // (count, mean, M2) row behind the tile rows), then the last group merges the group rows and writes the
-            // statistics.  Merging is the grouped formula (n = sum n_i, mean = sum n_i mean_i / n,
-            // M2 = sum M2_i + n_i (mean_i - mean)^2, evaluated about a shift) in a fixed order: deterministic whichever tile
-            // arrives last.
-            constexpr int NT = WGM * 128, TPC = NT / BN, UB = 8;
-            static_assert(NT % BN == 0 && TPC >= 1, "threads per column");
-            float* sh = (float*)smem;                                  // [TPC][BN][3]; the ring is free
-            int* flag = (int*)(sh + NT * 3);
-            const int tiles_m = a.tiles_m, ngroups = stat_groups(tiles_m);
-            const int col = tid % BN, sub = tid / BN, n = en0 + col;
-            const bool cok = n < argN;
-            const int grp = tm / kStatGroup;
-            int first = ngroups ? grp * kStatGroup : 0, count = ngroups ? min(kStatGroup, tiles_m - first) : tiles_m;
-            unsigned* ticket = ngroups ? a.bnf_tickets + a.tiles_n + tn * ngroups + grp : a.bnf_tickets + tn;
-            const unsigned st_bytes = (unsigned)min((unsigned long long)(tiles_m + ngroups) * argN * 12ull, 0x7fffff00ull);
-            const __amdgpu_buffer_rsrc_t rsS = make_rsrc(a.colstats, st_bytes);
-            float cnt = 0.f, mean = 0.f, m2 = 0.f;
-            bool early = true;                                         // the first hand-off's ticket was drawn before the epilogue
-#pragma unroll 1
-            for (int level = ngroups ? 0 : 1; level < 2; ++level) {
-                if (!early) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the group row's stores have left
-                    __syncthreads();
-                    if (tid == 0) bnf_drawn = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                early = false;
-                if (tid == 0) *flag = bnf_drawn;
-                __syncthreads();
-                const int drawn = *flag;
-                __syncthreads();
-                if (drawn != count - 1) return;                        // (workgroup-uniform)
-                if (tid == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the next launch
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                // one pass, every load of a batch in flight together (dependent passes cost a memory round trip each on the
-                // launch's tail).  Each thread sums n_i, n_i d_i and M2_i + n_i d_i^2 of its rows with d_i = mean_i - k, k = the
-                // mean of the thread's FIRST row (any row's mean is within a tile's standard error of the answer, so the final
-                // S2 - S1^2 / S0 cancels nothing; the first row rather than this workgroup's own tile so that the rounding does
-                // not depend on which tile arrived last); the TPC threads of a column then merge their triples the same way.
-                float k = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
-                for (int r0 = sub; r0 < count; r0 += TPC * UB) {
-                    float v[UB][3];
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) {
-                        const int r = r0 + u * TPC;
-                        const unsigned off = (cok && r < count) ? (unsigned)(((long long)(first + r) * argN + n) * 12) : kOOB;
-#pragma unroll
-                        for (int e = 0; e < 3; ++e)
-                            v[u][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsS, off + 4 * e, 0, 16 /* sc1: written by other XCDs */));
-                    }
-                    if (r0 == sub) k = v[0][1];
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) {                      // rows past the range read as zeros: no contribution
-                        const float c = v[u][0], d = v[u][1] - k;
-                        s0 += c;
-                        s1 = fmaf(c, d, s1);
-                        s2 += fmaf(c * d, d, v[u][2]);
-                    }
-                }
-                {
-                    const float dm = s0 > 0.f ? s1 / s0 : 0.f;
-                    sh[(sub * BN + col) * 3] = s0;
-                    sh[(sub * BN + col) * 3 + 1] = k + dm;
-                    sh[(sub * BN + col) * 3 + 2] = fmaxf(s2 - s1 * dm, 0.f);
-                }
-                __syncthreads();
-                k = sh[col * 3 + 1];                                   // thread 0 of the column always has a row
-                s0 = 0.f; s1 = 0.f; s2 = 0.f;
-#pragma unroll
-                for (int u = 0; u < TPC; ++u) {
-                    const float c = sh[(u * BN + col) * 3], d = sh[(u * BN + col) * 3 + 1] - k;
-                    s0 += c;
-                    s1 = fmaf(c, d, s1);
-                    s2 += fmaf(c * d, d, sh[(u * BN + col) * 3 + 2]);
-                }
-                __syncthreads();
-                cnt = s0;
-                const float dm = s0 > 0.f ? s1 / s0 : 0.f;
-                mean = k + dm;
-                m2 = fmaxf(s2 - s1 * dm, 0.f);
-                if (level == 0) {
-                    if (sub == 0 && cok) {
-                        float* o = a.colstats + ((long long)(tiles_m + grp) * argN + n) * 3;
-                        __hip_atomic_store(o, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(o + 1, mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(o + 2, m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    first = tiles_m;
-                    count = ngroups;
-                    ticket = a.bnf_tickets + tn;
-                }
-            }
-            if (sub == 0 && cok) {                                     // the launch's last workgroup of this column tile
-                const float rows = (float)argM;
-                const float var = m2 / rows;                           // biased, used for normalisation
-                const float invstd = rsqrtf(var + a.bnf_eps);
-                a.bnf_mean[n] = mean;
-                a.bnf_invstd[n] = invstd;
-                const float gm = a.bnf_gamma ? a.bnf_gamma[n] : 1.f, bt = a.bnf_beta ? a.bnf_beta[n] : 0.f;
-                a.bnf_scale[n] = gm * invstd;
-                a.bnf_shift[n] = bt - mean * gm * invstd;
-                if (a.bnf_rmean) {
-                    const float unbiased = argM > 1 ? m2 / (rows - 1.f) : var;
-                    a.bnf_rmean[n] = (1.f - a.bnf_momentum) * a.bnf_rmean[n] + a.bnf_momentum * mean;
-                    a.bnf_rvar[n] = (1.f - a.bnf_momentum) * a.bnf_rvar[n] + a.bnf_momentum * unbiased;
-                }
-            }
-        }
+        if (a.bnf_tickets) bnf_handoff<WGM * 128, BN>(a, smem, tid, tm, tn, en0, bnf_drawn);
     }
     if (!more) break;
     vb = nvb;

@@ -210,9 +210,9 @@ def cast_weights(tensors, device):
 #     shadows of weights that anything else touched (load_state_dict, torch.optim, manual init: all bump `_version`);
 #   * our other raw-pointer writer (FusedSGD) calls shadows_stale().
 # The registry on the C side (hs_weight_shadow_set) is keyed by the weight's address.
-# OFF by default (HAMSPINE_WEIGHT_SHADOWS=1 switches it on): measured on C2 it removes the 33 cast launches of a step and
-# changes nothing else -- 12.05-12.11 ms with, 12.02-12.05 ms without: the optimizer's extra 2 B per parameter and the casts'
-# 6 B per parameter both disappear inside an HBM-bound step tail.
+# ON by default since round 3 (HAMSPINE_WEIGHT_SHADOWS=0 switches it off).  Measured on C2: round 2 12.05-12.11 ms with,
+# 12.02-12.05 ms without (the casts hid inside an HBM-bound step tail); round 3, same box, three interleaved runs each:
+# 10.93-10.99 ms with, 11.05-11.08 ms without; kernel time 13.93 vs 14.09 ms per step (33 -> 5 cast launches).
 # ------------------------------------------------------------------------------------------------------------------
 import weakref as _weakref
 
@@ -226,7 +226,7 @@ class _Shadow:
 
 def shadows_enabled():
     import os
-    return os.environ.get("HAMSPINE_WEIGHT_SHADOWS", "0") == "1"
+    return os.environ.get("HAMSPINE_WEIGHT_SHADOWS", "1") != "0"
 
 
 def shadow_epoch():

@@ -444,6 +444,67 @@ def test_forward_gemm_finishes_the_batchnorm_statistics(case):
         assert ((rv.double() - rv_ref).abs() <= 1e-4 * rv_ref.abs()).all()
 
 
+# ---- the 3x3 halo-patch convolution kernel (csrc/conv3.hip) ---------------------------------------------------------------------
+C3_CASES = [
+    # Nb, Cin, H, W, Cout: rows per tile / tiles per image / row fragments, channel chunks
+    (3, 64, 56, 56, 64),       # 2 rows x 56, 28 tiles per image, 7 fragments, one chunk (ResNet50 layer1)
+    (2, 128, 28, 28, 128),     # 4 rows x 28, two chunks
+    (2, 256, 14, 14, 256),     # 7 x 14 = 98 pixels (14 padding rows in the last fragment), four chunks, four column tiles
+    (5, 512, 7, 7, 128),       # whole 7 x 7 image per tile, 4 fragments, eight chunks
+    (2, 64, 16, 16, 192),      # 6 + 6 + 4 rows: ragged last tile of every image
+    (3, 192, 10, 12, 64),      # 5 rows x 12 = 60 pixels: 4 fragments, three chunks (odd count: both loop parities end the walk)
+    (1, 320, 8, 8, 64),        # 64 pixels exactly, five chunks
+    (2, 64, 9, 80, 64),        # one image row per tile (80 pixels: 5 of the 7 fragments carry rows)
+]
+
+
+@pytest.mark.parametrize("with_stats", [False, True])
+@pytest.mark.parametrize("case", C3_CASES)
+def test_conv3x3_halo_kernel_matches_float64(case, with_stats):
+    """3x3 stride-1 pad-1 forward convolutions with a plain bf16 result take the halo-patch kernel (hs_gemm picks it; the same
+    call with an f32 result keeps the generic implicit GEMM and serves as a second reference): result within bf16 rounding of
+    the float64 convolution of the same bf16 operands, BatchNorm statistics (when asked for) as in
+    test_forward_gemm_finishes_the_batchnorm_statistics, zero padding exact, twice (the arrival counters re-arm)"""
+    Nb, Cin, H, Wd, N = case
+    g = torch.Generator().manual_seed(Nb * 1000 + Cin + H)
+    BF = torch.bfloat16
+    x = (torch.randn(Nb, Cin, H, Wd, generator=g) * 0.5).to(BF)
+    w = (torch.randn(N, Cin, 3, 3, generator=g) * 0.1).to(BF)
+    ref4 = torch.nn.functional.conv2d(x.double(), w.double(), stride=1, padding=1)
+    M, K = Nb * H * Wd, 9 * Cin
+    ref = ref4.permute(0, 2, 3, 1).reshape(M, N).to(DEV)
+    geom = raw.conv_geom(Nb, H, Wd, Cin, N, 3, 3, 1, 1)
+    xg = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    wg = w.to(DEV).contiguous(memory_format=torch.channels_last)
+    kw = dict(a_kind=L.A_CONV, b_kind=L.B_KC, ldb=K, geom=geom)
+    # the generic body, f32 result
+    D32 = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    raw.gemm(xg, wg, D32, M, N, K, ldd=N, **kw)
+    assert (D32.double() - ref).abs().max().item() <= 2e-5 * K * x.abs().max().item() * w.abs().max().item()
+    for rep in range(2):
+        D = torch.full((M, N), float("nan"), dtype=BF, device=DEV)
+        if not with_stats:
+            raw.gemm(xg, wg, D, M, N, K, ldd=N, **kw)
+        else:
+            gamma = (torch.rand(N, generator=g) + 0.5).to(DEV)
+            beta = (torch.randn(N, generator=g) * 0.3).to(DEV)
+            rm, rv = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+            D, mean, invstd, scale, shift = raw.gemm(xg, wg, D, M, N, K, ldd=N, **kw,
+                                                     bn_finish=dict(gamma=gamma, beta=beta, running_mean=rm, running_var=rv, eps=1e-5, momentum=0.1))
+            mean_ref, var_ref = ref.mean(0), ref.var(0, unbiased=False)
+            sd = var_ref.sqrt()
+            invstd_ref = 1.0 / (var_ref + 1e-5).sqrt()
+            assert ((mean.double() - mean_ref).abs() <= 1e-5 * (mean_ref.abs() + sd)).all(), rep
+            assert ((invstd.double() - invstd_ref).abs() <= 1e-4 * invstd_ref).all(), rep
+            assert ((scale.double() - gamma.double() * invstd_ref).abs() <= 1e-4 * (gamma.double() * invstd_ref).abs()).all()
+            assert ((rm.double() - 0.1 * mean_ref).abs() <= 1e-5 * (mean_ref.abs() + sd)).all()
+            assert ((rv.double() - (0.9 + 0.1 * var_ref * M / (M - 1))).abs() <= 1e-4 * (0.9 + 0.1 * var_ref)).all()
+        assert not torch.isnan(D.float()).any()
+        # the stored value is the bf16 rounding of an f32 accumulation: half an ulp of the result + the accumulation's own noise
+        assert ((D.double() - ref).abs() <= 2.0 ** -8 * ref.abs() + 2e-5 * K * 0.05).all(), rep
+        assert (D.double() - D32.double()).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+
+
 # ---- the phase-pipelined body (csrc/gemm_p8.h): 256x256 / 256x128 / 128x128 tiles, full tiles of nt GEMMs --------------------
 P8_CFGS = {7: (256, 256), 8: (256, 128), 9: (128, 128)}
 
