@@ -146,6 +146,13 @@ typedef struct hs_gemm_params {
        recomputed from c, and the launch may carry `residual` (the identity path's gradient, added BEFORE the sums are taken:
        reference torchvision Bottleneck.forward `out += identity; out = relu(out)`).  bnb_scale / bnb_shift are then unused. */
     const void* bnb_y;
+    /* optional (with bnb_partials, when hs_gemm_bnb_finish_rows(p) > 0): the launch also FINISHES that BatchNorm's backward sums --
+       the last workgroup of each column tile adds the tile rows' partials and writes bnb_finish->dbeta / dgamma and, behind
+       the hs_gemm_bnb_finish_rows(p) rows of bnb_partials, the four per-channel coefficient vectors of the apply pass
+       (gamma, M, training are read from *bnb_finish).  The caller then runs hs_batchnorm_bwd with ws = bnb_partials,
+       partial_rows = hs_gemm_bnb_finish_rows(p) and sums_done = 1 (apply pass only): one launch per BatchNorm less on the
+       stream (reference: torch's batch_norm_backward reduce + elementwise kernels). */
+    const struct hs_bn_bwd_params* bnb_finish;
 } hs_gemm_params;
 
 hs_status hs_gemm(const hs_gemm_params* p, void* stream);
@@ -156,6 +163,9 @@ int32_t hs_gemm_stat_rows(const hs_gemm_params* p);
 /* rows the colstats buffer needs when the launch for p (colstats set) can also finish the BatchNorm statistics
    (hs_gemm_params.bn_finish): tile rows + merge rows; 0 when this launch cannot. */
 int32_t hs_gemm_bn_finish_rows(const hs_gemm_params* p);
+/* rows bnb_partials must hold (tile rows + merge rows) when the launch for p can also finish the BatchNorm-backward sums
+   (hs_gemm_params.bnb_finish), else 0 (split-K launches, layouts without the rider). */
+int32_t hs_gemm_bnb_finish_rows(const hs_gemm_params* p);
 /* tile rows of the launch hs_gemm makes for p (p->split_k as it will be launched): rows of bnb_partials */
 int32_t hs_gemm_tile_rows(const hs_gemm_params* p);
 /* heuristic split-K factor for a (M,N,K) problem so that the grid fills 256 CUs. */
@@ -236,6 +246,9 @@ typedef struct hs_bn_bwd_params {
     const float* shift;
     /* > 0: ws already holds [partial_rows][C][2] backward sums (hs_gemm_params.bnb_partials): no partial pass is made */
     int32_t partial_rows;
+    /* 1 (with partial_rows > 0): the producing GEMM also finished the sums (hs_gemm_params.bnb_finish): dgamma / dbeta are
+       written and the coefficients sit behind the partial rows -- only the apply pass runs */
+    int32_t sums_done;
 } hs_bn_bwd_params;
 
 hs_status hs_batchnorm_fwd(const hs_bn_params* p, void* stream);

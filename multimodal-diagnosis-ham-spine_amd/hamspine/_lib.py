@@ -56,6 +56,7 @@ class GemmParams(C.Structure):
         ("bnb_x", vp), ("bnb_scale", vp), ("bnb_shift", vp), ("bnb_mean", vp), ("bnb_invstd", vp), ("bnb_partials", vp),
         ("bn_finish", vp),
         ("bnb_y", vp),
+        ("bnb_finish", vp),
     ]
 
 
@@ -75,7 +76,7 @@ class BnBwdParams(C.Structure):
         ("dtype", i32), ("C", i32), ("M", i64), ("training", i32), ("relu", i32),
         ("dy", vp), ("y", vp), ("x", vp), ("gamma", vp), ("save_mean", vp), ("save_invstd", vp),
         ("dx", vp), ("dres", vp), ("dgamma", vp), ("dbeta", vp), ("ws", vp), ("ws_bytes", i64),
-        ("scale", vp), ("shift", vp), ("partial_rows", i32),
+        ("scale", vp), ("shift", vp), ("partial_rows", i32), ("sums_done", i32),
     ]
 
 
@@ -177,6 +178,8 @@ def _declare(l):
     l.hs_gemm_stat_rows.argtypes = [P(GemmParams)]
     l.hs_gemm_bn_finish_rows.argtypes = [P(GemmParams)]
     l.hs_gemm_bn_finish_rows.restype = i32
+    l.hs_gemm_bnb_finish_rows.argtypes = [P(GemmParams)]
+    l.hs_gemm_bnb_finish_rows.restype = i32
     l.hs_gemm_tile_rows.argtypes = [P(GemmParams)]
     l.hs_gemm_tile_rows.restype = i32
     l.hs_gemm_suggest_split.argtypes = [i32] * 4

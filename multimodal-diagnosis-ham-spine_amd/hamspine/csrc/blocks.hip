@@ -25,6 +25,7 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream);
 int gemm_stat_rows(const hs_gemm_params* p);
 int gemm_bn_finish_rows(const hs_gemm_params* p);
 int gemm_tile_rows(const hs_gemm_params* p);
+int gemm_bnb_finish_rows(const hs_gemm_params* p);
 struct GemmGroup;
 GemmGroup* gemm_group_open(hipStream_t s, long long slot);   // slot: any key that is stable across steps (its device table is cached)
 int gemm_group_add(GemmGroup* g, const hs_gemm_params* p, hipStream_t s);
@@ -765,7 +766,20 @@ struct BnSums {
     long long partials_cap;     // bytes available at `partials` (incl. the 4*C coefficient floats behind the sums)
     int* rows;
     const void* y = nullptr;    // block-output form: dx (+ residual) is d relu(bn(c) + identity); the mask is y > 0 (hs_gemm_params.bnb_y)
+    // optional: the BatchNorm whose sums these are (C, M, training, gamma, dgamma, dbeta) -- the GEMM's last workgroups then also
+    // finish the sums (hs_gemm_params.bnb_finish) and *done = 1: hs_batchnorm_bwd runs its apply pass only
+    const hs_bn_bwd_params* finish = nullptr;
+    int* done = nullptr;
 };
+// MEASURED (round 3, rocprofv3, un-overlapped C2 step): with the sums finished inside the data-gradient GEMM the 37 rider launches
+// take 1.42 instead of 1.20 ms (+5.9 us each: write-through stores -> counter round trip -> the last workgroup's dependent
+// reads) and 32 bn_bwd_final launches (0.19 ms, 5.8 us each) go away: 14.18 vs 14.04 ms of kernels, 11.08 vs 11.08 ms per
+// overlapped step.  A per-layer reduction dependency costs ~6 us as a launch or as an in-launch tail.  OFF unless
+// HAMSPINE_BNB_FINISH=1.
+static bool bnb_finish_enabled() {
+    static const bool on = [] { const char* e = getenv("HAMSPINE_BNB_FINISH"); return e && e[0] == '1'; }();
+    return on;
+}
 static bool fused_bn_bwd_enabled() {        // HAMSPINE_FUSED_BN_BWD=0: BatchNorm backward makes its own partial-sum pass
     static int v = -1;
     if (v < 0) {
@@ -799,9 +813,16 @@ static int conv_dgrad_run(Run& r, const ConvShape& s, const void* dy, const void
         probe.bnb_x = bnb->c; probe.bnb_scale = bnb->scale; probe.bnb_shift = bnb->shift; probe.bnb_mean = bnb->mean;
         probe.bnb_invstd = bnb->invstd; probe.bnb_partials = bnb->partials; probe.bnb_y = bnb->y;
         const int rows = r.plan ? 0 : gemm_tile_rows(&probe);
+        if (bnb->done) *bnb->done = 0;
         if (rows > 0 && ((long long)rows * s.Cin * 2 + 4ll * s.Cin) * 4 <= bnb->partials_cap) {
             p = probe;
             *bnb->rows = rows;
+            const int frows = (bnb->finish && bnb->done && bnb_finish_enabled()) ? gemm_bnb_finish_rows(&probe) : 0;
+            if (frows > 0 && ((long long)frows * s.Cin * 2 + 4ll * s.Cin) * 4 <= bnb->partials_cap) {
+                p.bnb_finish = bnb->finish;
+                *bnb->rows = frows;
+                *bnb->done = 1;
+            }
         }
     }
     if (r.dt == HS_BF16 && s.stride == 1) return gemm_splitk(r, p);
@@ -991,6 +1012,7 @@ struct OwnSums {
     float* partials = nullptr;
     long long bytes = 0;
     int rows = 0;
+    int done = 0;      // the producing GEMM also finished the sums
 };
 static int resblock_bwd_run(Run& r, const hs_resblock_desc& d, const void* x, const void* y, const void* dy, void* dx,
                             const BnSums* next_bn = nullptr, const OwnSums* own = nullptr) {
@@ -1026,10 +1048,12 @@ static int resblock_bwd_run(Run& r, const hs_resblock_desc& d, const void* x, co
     HS_PROPAGATE(side_setup(r));
 
     auto bn_backward = [&](const hs_conv_bn& cb, const StageBuf& b, long long M, const void* g_out, const void* y_out,
-                           int relu, void* g_in_, void* g_res, int partial_rows = 0, const OwnSums* pre = nullptr) -> int {
+                           int relu, void* g_in_, void* g_res, int partial_rows = 0, const OwnSums* pre = nullptr,
+                           int sums_done = 0) -> int {
         hs_bn_bwd_params q;
         memset(&q, 0, sizeof(q));
         q.partial_rows = partial_rows;
+        q.sums_done = partial_rows > 0 ? sums_done : 0;
         q.dtype = r.dt; q.C = cb.Cout; q.M = M;
         q.training = d.training; q.relu = relu;
         q.dy = g_out; q.y = y_out; q.x = b.c;
@@ -1045,6 +1069,7 @@ static int resblock_bwd_run(Run& r, const hs_resblock_desc& d, const void* x, co
         q.ws = L.bn_ws; q.ws_bytes = L.bn_ws_bytes;
         if (pre && pre->rows > 0) {               // the sums came with the gradient (another block's data-gradient GEMM)
             q.partial_rows = pre->rows;
+            q.sums_done = pre->done;
             q.ws = pre->partials; q.ws_bytes = pre->bytes;
         }
         CALLK(r, 16, hs_batchnorm_bwd(&q, r.s));
@@ -1071,11 +1096,22 @@ static int resblock_bwd_run(Run& r, const hs_resblock_desc& d, const void* x, co
         } else {
             // the data gradient of stage i is d relu(bn(c)) of stage i - 1: its GEMM takes that BatchNorm's backward sums along
             const StageBuf& pb = L.main[i - 1];
-            int sum_rows = 0;
-            BnSums bs = {pb.c, pb.scale, pb.shift, pb.mean, pb.invstd, (float*)L.bn_ws, L.bn_ws_bytes, &sum_rows};
-            HS_PROPAGATE(conv_dgrad_run(r, b.s, g_conv[i], b.w_c, g_in[i], nullptr, &bs));
+            int sum_rows = 0, sum_done = 0;
             const long long Mp = (long long)d.N * pb.s.P * pb.s.Q;
-            HS_PROPAGATE(bn_backward(d.main[i - 1], pb, Mp, g_in[i], pb.a, 1, g_conv[i - 1], nullptr, sum_rows));
+            const hs_conv_bn& pcb = d.main[i - 1];
+            hs_bn_bwd_params fin;                 // what the GEMM's finishing workgroups need of that BatchNorm
+            memset(&fin, 0, sizeof(fin));
+            fin.dtype = r.dt; fin.C = pcb.Cout; fin.M = Mp; fin.training = d.training;
+            fin.gamma = pcb.gamma;
+            fin.dgamma = pcb.dgamma ? pcb.dgamma : scratch_pg;
+            fin.dbeta = pcb.dbeta ? pcb.dbeta : (scratch_pg ? scratch_pg + 4096 : nullptr);
+            BnSums bs = {pb.c, pb.scale, pb.shift, pb.mean, pb.invstd, (float*)L.bn_ws, L.bn_ws_bytes, &sum_rows};
+            if (fin.dgamma && fin.dbeta) {
+                bs.finish = &fin;
+                bs.done = &sum_done;
+            }
+            HS_PROPAGATE(conv_dgrad_run(r, b.s, g_conv[i], b.w_c, g_in[i], nullptr, &bs));
+            HS_PROPAGATE(bn_backward(d.main[i - 1], pb, Mp, g_in[i], pb.a, 1, g_conv[i - 1], nullptr, sum_rows, nullptr, sum_done));
         }
     }
     HS_PROPAGATE(side_join(r));
@@ -1627,13 +1663,14 @@ static int resnet_bwd_run(Run& r, const hs_resnet_desc& d, const void* const* dy
         int C, H, W;
         const long long ob = out_bytes_of(d.blocks[i], dt, &C, &H, &W);
         const long long rows = (ob / esize(dt) / C + 63) / 64;
-        xs_bytes = std::max<long long>(xs_bytes, (rows * C * 2 + 4ll * C) * 4);
+        xs_bytes = std::max<long long>(xs_bytes, ((rows + rows / 32 + 2) * C * 2 + 4ll * C) * 4);   // tile rows + merge rows + coefficients
     }
     float* xs_buf[2] = {(float*)r.ws.alloc(xs_bytes), (float*)r.ws.alloc(xs_bytes)};
     OwnSums own_next;                 // sums of the block about to be processed, if the previous iteration produced them
     const char* xb_env = getenv("HAMSPINE_XBLOCK_BN");       // read per call: tests compare both settings in one process
     const int xblock = xb_env ? atoi(xb_env) : 1;
-    int xs_rows = 0;
+    int xs_rows = 0, xs_done = 0;
+    hs_bn_bwd_params xs_fin;
     for (int i = d.n_blocks - 1; i >= 0; --i) {
         const bool is_tap = tap >= 0 && d.tap_block[tap] == i;
         const void* ext = is_tap && dy_taps ? dy_taps[tap] : nullptr;
@@ -1669,14 +1706,23 @@ static int resnet_bwd_run(Run& r, const hs_resnet_desc& d, const void* const* dy
             r.saved.off = keep_saved;
             r.ws.release(keep_ws);
             xs_rows = 0;
+            xs_done = 0;
             next_bn = BnSums{lb.c, lb.scale, lb.shift, lb.mean, lb.invstd, xs_buf[i & 1], xs_bytes, &xs_rows, x};
+            const hs_conv_bn& pcb = pb.main[pb.n_main - 1];
+            memset(&xs_fin, 0, sizeof(xs_fin));
+            xs_fin.dtype = dt; xs_fin.C = pcb.Cout; xs_fin.M = (long long)pb.N * lb.s.P * lb.s.Q; xs_fin.training = pb.training;
+            xs_fin.gamma = pcb.gamma; xs_fin.dgamma = pcb.dgamma; xs_fin.dbeta = pcb.dbeta;
+            if (pcb.dgamma && pcb.dbeta) {
+                next_bn.finish = &xs_fin;
+                next_bn.done = &xs_done;
+            }
             nb = &next_bn;
         }
         r.saved.off = lo.lay_off[i + 1];
         const long long wm = r.ws.mark();
         HS_PROPAGATE(resblock_bwd_run(r, d.blocks[i], x, y, dy, dx, nb, own_next.rows > 0 ? &own_next : nullptr));
         own_next = OwnSums{};
-        if (nb && xs_rows > 0) own_next = OwnSums{xs_buf[i & 1], xs_bytes, xs_rows};
+        if (nb && xs_rows > 0) own_next = OwnSums{xs_buf[i & 1], xs_bytes, xs_rows, xs_done};
         if (!r.defer_wgrad) r.ws.release(wm);
         dy = dx;
         cur ^= 1;

@@ -433,6 +433,17 @@ static int gemm_prepare(const hs_gemm_params* p, hipStream_t stream, Prepared& q
         }
     }
     if (a.colstats) HS_REQUIRE(bf16 && split == 1 && batch == 1, "hs_gemm: colstats needs bf16 operands, no split-K, no batch");
+    if (p->bnb_finish) {       // the launch also finishes the BatchNorm-backward sums (bnb_handoff; hs_gemm_bnb_finish_rows said it can)
+        const hs_bn_bwd_params* f = p->bnb_finish;
+        HS_REQUIRE(a.bnb_partials && split == 1 && (cfg == CFG_64x64 || cfg == CFG_128x64) && a.persist == 0,
+                   "hs_gemm: bnb_finish needs bnb_partials and a launch hs_gemm_bnb_finish_rows accepts");
+        HS_REQUIRE(f->C == p->N && f->M > 0 && f->dgamma && f->dbeta, "hs_gemm: bnb_finish needs the BatchNorm's C, M, dgamma, dbeta");
+        HS_REQUIRE((long long)a.tiles_n * (1 + stat_groups(a.tiles_m)) <= kTicketPool, "hs_gemm: bnb_finish: too many column tiles");
+        a.bnb_gamma = f->gamma; a.bnb_dgamma = f->dgamma; a.bnb_dbeta = f->dbeta;
+        a.bnb_invm = 1.f / (float)f->M; a.bnb_train = f->training;
+        a.bnb_tickets = ticket_pool(stream);
+        HS_REQUIRE(a.bnb_tickets != nullptr, "hs_gemm: cannot allocate the arrival counters");
+    }
     if (p->bn_finish) {        // the launch also finishes the BatchNorm statistics (BNF kernels; hs_gemm_bn_finish_rows said it can)
         const hs_bn_params* f = p->bn_finish;
         HS_REQUIRE(a.colstats && bn_finish_variant(cfg, combo), "hs_gemm: bn_finish needs colstats and a tile / layout hs_gemm_bn_finish_rows accepts");
@@ -534,6 +545,20 @@ int gemm_bn_finish_rows(const hs_gemm_params* p) {
     Prepared q;
     if (gemm_prepare(&c, nullptr, q) != HS_OK) return 0;
     if (!q.bf16 || q.split != 1 || q.batch != 1 || q.a.persist > 0 || !bn_finish_variant(q.cfg, q.combo)) return 0;
+    if ((long long)q.a.tiles_n * (1 + stat_groups(q.a.tiles_m)) > kTicketPool) return 0;
+    return q.a.tiles_m + stat_groups(q.a.tiles_m);
+}
+
+// rows of the bnb_partials buffer when the launch for p can also finish the BatchNorm-backward sums (tile rows + group rows), else 0
+int gemm_bnb_finish_rows(const hs_gemm_params* p) {
+    if (!p || !p->bnb_partials) return 0;
+    hs_gemm_params c = *p;
+    c.bnb_finish = nullptr;
+    unsigned char dummy[16];
+    if (c.split_k > 1 && !c.splitk_ws) c.splitk_ws = (float*)dummy;
+    Prepared q;
+    if (gemm_prepare(&c, nullptr, q) != HS_OK) return 0;
+    if (!q.bf16 || q.split != 1 || q.batch != 1 || q.a.persist > 0 || !(q.cfg == CFG_64x64 || q.cfg == CFG_128x64)) return 0;
     if ((long long)q.a.tiles_n * (1 + stat_groups(q.a.tiles_m)) > kTicketPool) return 0;
     return q.a.tiles_m + stat_groups(q.a.tiles_m);
 }
@@ -786,6 +811,7 @@ int hs_device_ok(void) {
 hs_status hs_gemm(const hs_gemm_params* p, void* stream) { return hs::gemm_impl(p, (hipStream_t)stream); }
 int32_t hs_gemm_stat_rows(const hs_gemm_params* p) { return hs::gemm_stat_rows(p); }
 int32_t hs_gemm_bn_finish_rows(const hs_gemm_params* p) { return hs::gemm_bn_finish_rows(p); }
+int32_t hs_gemm_bnb_finish_rows(const hs_gemm_params* p) { return hs::gemm_bnb_finish_rows(p); }
 int32_t hs_gemm_tile_rows(const hs_gemm_params* p) { return hs::gemm_tile_rows(p); }
 int64_t hs_gemm_splitk_ws_bytes(const hs_gemm_params* p) {
     if (!p || p->split_k <= 1) return 0;

@@ -73,6 +73,14 @@ struct GemmArgs {
     const float *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd;
     float* bnb_partials;
     const char* bnb_y;         // optional: the mask comes from this saved block output (y > 0) and a.residual is added before the sums
+    // optional (with bnb_partials, split_k == 1): the launch also FINISHES that BatchNorm's backward sums -- the last workgroup of
+    // a column tile adds the tile rows' partials and writes dbeta, dgamma and the four coefficient vectors of the apply pass
+    // behind the partial rows (hs_gemm_params.bnb_finish; bnb_handoff below).  bnb_tickets: zeroed arrival counters as for bnf.
+    const float* bnb_gamma;
+    float *bnb_dgamma, *bnb_dbeta;
+    float bnb_invm;
+    int bnb_train;
+    unsigned* bnb_tickets;
     // optional (BNF kernels, with colstats): the launch also FINISHES the following BatchNorm's statistics -- the last workgroup
     // of a column tile merges the row tiles' partials and writes mean / invstd / scale / shift (+ running statistics); see
     // hs_gemm_params.bn_finish.  bnf_tickets: tiles_n * (1 + stat_groups(tiles_m)) zeroed arrival counters.
@@ -749,6 +757,97 @@ __device__ __forceinline__ void bnf_handoff(const GemmArgs& a, char* smem, const
         }
     }
 }
+// ---- BatchNorm-backward sums hand-off of a data-gradient GEMM (BNS kernels) ----------------------------------------------------
+// Same protocol as bnf_handoff with plain sums: partial row tm = (sum dz, sum dz * xhat) per column; the last tile row of a
+// group of kStatGroup adds the group into a row behind the tile rows, the last group adds the group rows and writes what
+// bn_bwd_final_kernel (norm.hip) writes: dbeta, dgamma and coef = [ca | cb | cc | mean] behind all rows.  Fixed summation
+// order whichever workgroup arrives last.
+template <int NT, int BN>
+__device__ __forceinline__ void bnb_handoff(const GemmArgs& a, char* smem, const int tid, const int tm, const int tn, const int en0,
+                                            int drawn_) {
+    constexpr int TPC = NT / BN, UB = 8;
+    static_assert(NT % BN == 0 && TPC >= 1, "threads per column");
+    float* sh = (float*)smem;                                  // [TPC][BN][2]; the ring is free
+    int* flag = (int*)(sh + NT * 2);
+    const int tiles_m = a.tiles_m, ngroups = stat_groups(tiles_m);
+    const int col = tid % BN, sub = tid / BN, n = en0 + col;
+    const bool cok = n < a.N;
+    const int grp = tm / kStatGroup;
+    int first = ngroups ? grp * kStatGroup : 0, count = ngroups ? min(kStatGroup, tiles_m - first) : tiles_m;
+    unsigned* ticket = ngroups ? a.bnb_tickets + a.tiles_n + tn * ngroups + grp : a.bnb_tickets + tn;
+    const unsigned st_bytes = (unsigned)min((unsigned long long)(tiles_m + ngroups) * a.N * 8ull, 0x7fffff00ull);
+    const __amdgpu_buffer_rsrc_t rsS = make_rsrc(a.bnb_partials, st_bytes);
+    float t1 = 0.f, t2 = 0.f;
+    bool early = true;
+#pragma unroll 1
+    for (int level = ngroups ? 0 : 1; level < 2; ++level) {
+        if (!early) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the group row's stores have left
+            __syncthreads();
+            if (tid == 0) drawn_ = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        early = false;
+        if (tid == 0) *flag = drawn_;
+        __syncthreads();
+        const int drawn = *flag;
+        __syncthreads();
+        if (drawn != count - 1) return;                        // (workgroup-uniform)
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the next launch
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float s1 = 0.f, s2 = 0.f;
+        for (int r0 = sub; r0 < count; r0 += TPC * UB) {
+            float v[UB][2];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int r = r0 + u * TPC;
+                const unsigned off = (cok && r < count) ? (unsigned)(((long long)(first + r) * a.N + n) * 8) : kOOB;
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    v[u][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsS, off + 4 * e, 0, 16 /* sc1: written by other XCDs */));
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {                      // rows past the range read as zeros
+                s1 += v[u][0];
+                s2 += v[u][1];
+            }
+        }
+        sh[(sub * BN + col) * 2] = s1;
+        sh[(sub * BN + col) * 2 + 1] = s2;
+        __syncthreads();
+        t1 = 0.f; t2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < TPC; ++u) {
+            t1 += sh[(u * BN + col) * 2];
+            t2 += sh[(u * BN + col) * 2 + 1];
+        }
+        __syncthreads();
+        if (level == 0) {
+            if (sub == 0 && cok) {
+                float* o = a.bnb_partials + ((long long)(tiles_m + grp) * a.N + n) * 2;
+                __hip_atomic_store(o, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(o + 1, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            first = tiles_m;
+            count = ngroups;
+            ticket = a.bnb_tickets + tn;
+        }
+    }
+    if (sub == 0 && cok) {                                     // the launch's last workgroup of this column tile
+        float* coef = a.bnb_partials + (long long)(tiles_m + ngroups) * a.N * 2;
+        a.bnb_dbeta[n] = t1;
+        a.bnb_dgamma[n] = t2;
+        const float gm = a.bnb_gamma ? a.bnb_gamma[n] : 1.f, is = a.bnb_invstd[n];
+        const float ca = gm * is;
+        coef[n] = ca;
+        coef[a.N + n] = a.bnb_train ? -ca * is * t2 * a.bnb_invm : 0.f;
+        coef[2 * a.N + n] = a.bnb_train ? -ca * t1 * a.bnb_invm : 0.f;
+        coef[3 * a.N + n] = a.bnb_mean[n];
+    }
+}
 // SK: the launch may be a split-K one (false: the slab / hand-off code is left out -- its registers count against every launch).
 // PS: persistent-capable (the tile loop and the next-tile prefetch are compiled in; costs registers, so it is a variant).
 // BNS: the epilogue can also take the BatchNorm-backward sums of the result (a.bnb_partials; data gradients of ResNet blocks).
@@ -1335,6 +1434,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
     // Block-output form (a.bnb_y): the result + a.residual is the gradient of relu(bn(c) + identity); the residual is added
     // HERE (the epilogue below then runs without it) and the mask is y > 0 on the saved block output.
     bool res_consumed = false;
+    int bnb_drawn = 0;
     if constexpr (BNS) {
         if (a.bnb_partials) {
             const bool from_y = a.bnb_y != nullptr;
@@ -1429,10 +1529,22 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
                     t2 += sh2[(w * BN + tid) * 2 + 1];
                 }
                 float* o = a.bnb_partials + ((long long)tm * argN + n0 + tid) * 2;
-                o[0] = t1;
-                o[1] = t2;
+                if (a.bnb_tickets) {               // read by another workgroup of this launch: write-through
+                    __hip_atomic_store(o, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(o + 1, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    o[0] = t1;
+                    o[1] = t2;
+                }
             }
             __syncthreads();                       // (persistent variants reuse the ring right after)
+            if (a.bnb_tickets) {                   // arrival drawn here: the counter's round trip runs under the epilogue
+                const int ng = stat_groups(a.tiles_m);
+                unsigned* ticket = ng ? a.bnb_tickets + a.tiles_n + tn * ng + tm / kStatGroup : a.bnb_tickets + tn;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the partial stores have left
+                __syncthreads();
+                if (tid == 0) bnb_drawn = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     // ---- next tile's set-up and first operand slots go out before this tile's epilogue (persistent launches) ----------
@@ -1479,6 +1591,9 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bx, 
     HS_STAMP(4);
     if constexpr (BNF && !PS) {
         if (a.bnf_tickets) bnf_handoff<WGM * 128, BN>(a, smem, tid, tm, tn, en0, bnf_drawn);
+    }
+    if constexpr (BNS && !PS) {
+        if (a.bnb_partials && a.bnb_tickets) bnb_handoff<WGM * 128, BN>(a, smem, tid, tm, tn, en0, bnb_drawn);
     }
     if (!more) break;
     vb = nvb;

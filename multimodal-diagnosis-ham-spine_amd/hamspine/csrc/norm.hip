@@ -449,9 +449,11 @@ static int bn_bwd_t(const hs_bn_bwd_params* p, hipStream_t s) {
                            (const T*)p->x, p->save_mean, p->save_invstd, M, C, g.tpc, p->relu, (float*)p->ws, p->scale, p->shift);
         HS_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, (const float*)p->ws, g.gy, C, p->gamma,
-                       p->save_mean, p->save_invstd, 1.f / (float)M, p->training, p->dbeta, p->dgamma, coef);
-    HS_LAUNCH_CHECK();
+    if (!(p->partial_rows > 0 && p->sums_done)) {          // (sums_done: the producing GEMM's last workgroups wrote dbeta / dgamma / coef)
+        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, (const float*)p->ws, g.gy, C, p->gamma,
+                           p->save_mean, p->save_invstd, 1.f / (float)M, p->training, p->dbeta, p->dgamma, coef);
+        HS_LAUNCH_CHECK();
+    }
     if (p->dx) {
         const long long nch = M * C / E;
         const int blocks = (int)std::min<long long>((nch + 255) / 256, 4096);

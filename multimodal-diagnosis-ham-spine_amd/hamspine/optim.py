@@ -26,7 +26,7 @@ _KNOCK_ADAM = None
 class _FusedAdamBase(torch.optim.Optimizer):
     _decoupled = True
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, overlap_backward=False,
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, overlap_backward=None,
                  overlap_chunk=8 << 20):
         """overlap_backward: update parameters while backward is still running -- as soon as `overlap_chunk` elements
         worth of gradients are final (post-accumulate hooks) their fused update is enqueued on a side stream ordered
@@ -35,8 +35,10 @@ class _FusedAdamBase(torch.optim.Optimizer):
         clipping, no gradient accumulation over several backwards), which is how the reference trains
         (scripts/train.py:373-385, mibf_net/train_resnet.py:29-33)."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if overlap_backward is None:       # (HAMSPINE_ADAM_OVERLAP=1: A/B measurements of the mode without touching the caller)
+            overlap_backward = _os.environ.get("HAMSPINE_ADAM_OVERLAP", "0") == "1"
         self._overlap = bool(overlap_backward)
-        self._chunk = int(overlap_chunk)
+        self._chunk = int(_os.environ.get("HAMSPINE_ADAM_CHUNK", "0")) << 20 or int(overlap_chunk)
         self._pending, self._pending_n = [], 0
         self._pending_streams = {}      # streams the pending gradients became final on (id -> torch.cuda.Stream)
         self._stream = None

@@ -49,12 +49,14 @@ def gemm(A, B, D, M, N, K, a_kind=L.A_KC, b_kind=L.B_KC, lda=0, ldb=0, ldd=None,
          batch=1, batch_inner=1, a_bs=(0, 0), b_bs=(0, 0), d_bs=(0, 0), split_k=1,
          alpha=1.0, bias=None, act=L.ACT_NONE, preact=None, residual=None, ldr=None,
          dropout_p=0.0, dropout_seed=0, mul_mode=L.MUL_NONE, mul_src=None, ldm=None, accumulate=False, rowsum_a=None, bnb=None,
-         bn_finish=None):
+         bn_finish=None, bnb_finish=None):
     """D[m][n] = epi(alpha * sum_k A(m,k) B(n,k)); see include/hamspine.h for the operand kinds.
     bn_finish = dict(gamma, beta, running_mean, running_var, eps, momentum): the launch also produces the train-mode
     BatchNorm statistics of the result (hs_gemm_params.colstats + .bn_finish); returns (D, mean, invstd, scale, shift).
     bnb = (c, scale, shift, mean, invstd): also return the BatchNorm-backward partial sums of the result
-    (hs_gemm_params.bnb_*) as a float tensor [tile rows][N][2]."""
+    (hs_gemm_params.bnb_*) as a float tensor [tile rows][N][2].
+    bnb_finish = dict(gamma, training) (with bnb): the launch also finishes those sums (hs_gemm_params.bnb_finish); returns
+    (D, partial rows, dgamma, dbeta, coef [4][N])."""
     need_gpu(A, B, D, bias, preact, residual, mul_src, rowsum_a)
     p = L.GemmParams()
     p.dtype = hs_dtype(A)
@@ -106,8 +108,24 @@ def gemm(A, B, D, M, N, K, a_kind=L.A_KC, b_kind=L.B_KC, lda=0, ldb=0, ldd=None,
         rows = int(L.lib().hs_gemm_tile_rows(C.byref(p)))
         if rows <= 0:
             raise L.HamspineError("gemm: bnb is not available for this configuration")
-        partials = torch.empty((rows, N, 2), dtype=torch.float32, device=A.device)
-        p.bnb_partials = ptr(partials)
+        fin = None
+        if bnb_finish is not None:
+            frows = int(L.lib().hs_gemm_bnb_finish_rows(C.byref(p)))
+            if frows <= 0:
+                raise L.HamspineError("gemm: bnb_finish is not available for this configuration")
+            buf = torch.full((frows * N * 2 + 4 * N,), float("nan"), dtype=torch.float32, device=A.device)
+            partials = buf[:rows * N * 2].view(rows, N, 2)
+            dgamma, dbeta = (torch.full((N,), float("nan"), dtype=torch.float32, device=A.device) for _ in range(2))
+            need_gpu(bnb_finish.get("gamma"))
+            fq = L.BnBwdParams()
+            fq.dtype, fq.C, fq.M, fq.training = p.dtype, N, M, int(bnb_finish.get("training", 1))
+            fq.gamma, fq.dgamma, fq.dbeta = ptr(bnb_finish.get("gamma")), ptr(dgamma), ptr(dbeta)
+            p.bnb_partials = ptr(buf)
+            p.bnb_finish = C.addressof(fq)
+            fin = (fq, dgamma, dbeta, buf[frows * N * 2:].view(4, N))
+        else:
+            partials = torch.empty((rows, N, 2), dtype=torch.float32, device=A.device)
+            p.bnb_partials = ptr(partials)
     if bn_finish is not None:
         f = bn_finish
         p.colstats = 16                  # any non-null value: the row query only looks at the configuration
@@ -129,6 +147,8 @@ def gemm(A, B, D, M, N, K, a_kind=L.A_KC, b_kind=L.B_KC, lda=0, ldb=0, ldd=None,
         L.check(L.lib().hs_gemm(C.byref(p), stream_ptr()), "hs_gemm")
         return (D, *out)
     L.check(L.lib().hs_gemm(C.byref(p), stream_ptr()), "hs_gemm")
+    if bnb is not None and bnb_finish is not None:
+        return (D, partials, fin[1], fin[2], fin[3])
     return (D, partials) if bnb is not None else D
 
 

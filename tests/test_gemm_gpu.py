@@ -357,6 +357,51 @@ def test_data_gradient_gemm_takes_the_batchnorm_backward_sums(M, N, K, split):
     assert ((s[:, 1] - want2).abs() <= tol2).all()
 
 
+@pytest.mark.parametrize("M,N,K,block_form", [(6272, 256, 1024, False), (100352, 64, 256, False), (1000, 72, 320, False), (6272, 1024, 256, True),
+                                              (25088 + 8, 128, 512, True)])
+def test_data_gradient_gemm_finishes_the_batchnorm_backward_sums(M, N, K, block_form):
+    """hs_gemm_params.bnb_finish: the launch's last workgroups add the tile rows' sums and write dbeta, dgamma and the apply
+    pass's coefficient vectors [g*is | -g*is^2*dgamma/M | -g*is*dbeta/M | mean] (what bn_bwd_final_kernel writes): one merge level,
+    two levels (1568 tile rows), ragged tiles, both forms of the rider, twice (the arrival counters re-arm)"""
+    g = torch.Generator().manual_seed(M + N + 11)
+    BF = torch.bfloat16
+    dy = (torch.randn(M, K, generator=g) * 0.5).to(BF).to(DEV)
+    W = (torch.randn(K, N, generator=g) * 0.1).to(BF).to(DEV)
+    c = torch.randn(M, N, generator=g).to(BF).to(DEV)
+    y = torch.relu(torch.randn(M, N, generator=g)).to(BF).to(DEV)
+    gamma = torch.rand(N, generator=g) + 0.5
+    beta = torch.randn(N, generator=g) * 0.3
+    mean, invstd = torch.randn(N, generator=g) * 0.2, torch.rand(N, generator=g) + 0.5
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    dev = lambda t: t.float().to(DEV)
+    for rep in range(2):
+        D = torch.full((M, N), float("nan"), dtype=BF, device=DEV)
+        bnb = (c, dev(scale), dev(shift), dev(mean), dev(invstd)) + ((y,) if block_form else ())
+        D, part, dgamma, dbeta, coef = raw.gemm(dy, W, D, M, N, K, a_kind=L.A_KC, b_kind=L.B_RC, lda=K, ldb=N, bnb=bnb,
+                                                bnb_finish=dict(gamma=dev(gamma), training=1))
+        dd, cd = D.double().cpu(), c.double().cpu()
+        if block_form:
+            mask = (y.double().cpu() > 0).double()
+        else:
+            mask = (torch.addcmul(dev(shift).cpu().float(), c.float().cpu(), dev(scale).cpu().float()) > 0).double()
+        dz = dd * mask
+        xhat = (cd - mean.float().double()) * invstd.float().double()
+        want1, want2 = dz.sum(0), (dz * xhat).sum(0)
+        tol1 = 1e-4 * dz.abs().sum(0) + 1e-6
+        tol2 = 1e-4 * (dz * xhat).abs().sum(0) + 1e-6
+        assert ((part.double().cpu().sum(0)[:, 0] - want1).abs() <= tol1).all(), rep
+        assert ((dbeta.double().cpu() - want1).abs() <= tol1).all(), rep
+        assert ((dgamma.double().cpu() - want2).abs() <= tol2).all(), rep
+        gi = (gamma.float() * invstd.float()).double()
+        co = coef.double().cpu()
+        assert ((co[0] - gi).abs() <= 1e-6 * gi.abs()).all()
+        cb_ref, cc_ref = -gi * invstd.float().double() * want2 / M, -gi * want1 / M
+        assert ((co[1] - cb_ref).abs() <= 1e-4 * (gi * invstd.double() * (dz * xhat).abs().sum(0) / M) + 1e-9).all()
+        assert ((co[2] - cc_ref).abs() <= 1e-4 * (gi * dz.abs().sum(0) / M) + 1e-9).all()
+        assert torch.equal(co[3].float(), mean.float())
+
+
 @pytest.mark.parametrize("M,N,K,with_res", [(6272, 1024, 256, True), (100352, 256, 64, True), (1000, 72 + 8, 320, True), (25088, 512, 128, False)])
 def test_data_gradient_gemm_takes_the_block_final_batchnorm_sums(M, N, K, with_res):
     """block-output form of the rider (hs_gemm_params.bnb_y): dx = dy W + identity-path gradient is the gradient of
