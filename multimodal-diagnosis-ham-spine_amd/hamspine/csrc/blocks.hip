@@ -72,6 +72,9 @@ struct Run {
     // end of the layer (group_nt is set in plan mode too: it decides what scratch the layer needs)
     bool group_nt = false;
     GemmGroup* grp_nt = nullptr;
+    // BERT tower backward: the group above belongs to the TOWER and spans several layers (bert_bwd_run opens and flushes it);
+    // a layer then neither opens nor flushes, and the tower keeps the layers' transposed operands allocated until the flush
+    GemmGroup* tower_grp = nullptr;
 };
 
 // one non-blocking side stream and a ring of events per device (events are re-recordable; every composite joins
@@ -1426,7 +1429,7 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
         // one cached problem table per layer, keyed by the layer's WEIGHT pointer: stable across steps (a gradient pointer is
         // not -- models that allocate fresh gradient memory per backward would add a table per address -- and is NULL for a
         // frozen weight, which would collide with the image tower's slots 0 / 1); + 16 keeps it clear of slots -1, 0, 1
-        r.grp_nt = gemm_group_open(r.s, (long long)(uintptr_t)d.q.w + 16);
+        r.grp_nt = r.tower_grp ? r.tower_grp : gemm_group_open(r.s, (long long)(uintptr_t)d.q.w + 16);
         HS_REQUIRE(r.grp_nt != nullptr, "bert_layer_bwd: cannot set up the grouped weight-gradient launch");
     }
     // X^T of the four saved activations the weight gradients read: all known when the layer's backward starts, so they are
@@ -1561,7 +1564,7 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
         // dx = dqkv Wqkv + dh1 (residual of the attention-output LN input)
         HS_PROPAGATE(linear_dgrad_run(r, qkv_lin, L.wqkv, dqkv, M, 3 * Hd, dx, Hd, r.dt, HS_MUL_NONE, nullptr, 0, dh1, wqkv_t));
     }
-    if (r.group_nt && !r.plan) HS_PROPAGATE(gemm_group_flush(r.grp_nt, r.s));
+    if (r.group_nt && !r.plan && !r.tower_grp) HS_PROPAGATE(gemm_group_flush(r.grp_nt, r.s));
     r.group_nt = false;
     HS_PROPAGATE(side_join(r));
     RUN_CHECK_ARENAS(r, "bert_layer_bwd");
@@ -1796,17 +1799,35 @@ static int bert_bwd_run(Run& r, const hs_bert_desc& d, const int64_t* ids, const
     int cur = 0;
     const void* dy = dy_in;
     char* base = r.saved.base;
+    // The K-contiguous weight-gradient GEMMs of `span` consecutive layers run as ONE grouped grid (BERT-base, two layers: 8
+    // GEMMs = 216 tiles of 256 x 256, one per CU, K = 4096: the phase-pipelined body's steady state -- alone a layer is 108
+    // such tiles, or 216 of 256 x 128 on the generic body at half the rate).  The layers' transposed operands stay allocated
+    // until the flush; HAMSPINE_WGRAD_LAYERS=1 flushes per layer (round 2 behaviour).
+    static const int span = [] { const char* e = getenv("HAMSPINE_WGRAD_LAYERS"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 8 ? v : 2; }();
+    int pending = 0;
+    long long wm = 0;
+    const void* gps[8][16];
     for (int i = d.n_layers - 1; i >= 0; --i) {
         const hs_bert_layer_desc l = bert_layer_of(d, i, mask);
         char* dx = gbuf[cur];
         r.saved.off = lo.lay_off[i + 1];
-        const long long wm = r.ws.mark();
+        if (pending == 0) {
+            wm = r.ws.mark();
+            r.tower_grp = (span > 1 && !r.plan) ? gemm_group_open(r.s, (long long)(uintptr_t)l.q.w + 24) : nullptr;
+        }
         HS_PROPAGATE(bert_layer_bwd_run(r, l, base ? base + lo.y_off[i] : nullptr, dy, dx));
-        r.ws.release(wm);
         {
             const void* gp[16] = {l.q.dw, l.q.db, l.k.dw, l.k.db, l.v.dw, l.v.db, l.ao.dw, l.ao.db, l.ln1.dgamma, l.ln1.dbeta,
                                   l.inter_l.dw, l.inter_l.db, l.out_l.dw, l.out_l.db, l.ln2.dgamma, l.ln2.dbeta};
-            HS_PROPAGATE(milestones_hit(r, gp, 16));
+            memcpy(gps[pending], gp, sizeof(gp));
+        }
+        ++pending;
+        if (pending == span || i == 0) {
+            if (r.tower_grp) HS_PROPAGATE(gemm_group_flush(r.tower_grp, r.s));
+            r.tower_grp = nullptr;
+            r.ws.release(wm);
+            for (int k = 0; k < pending; ++k) HS_PROPAGATE(milestones_hit(r, gps[k], 16));
+            pending = 0;
         }
         dy = dx;
         cur ^= 1;

@@ -601,6 +601,8 @@ int gemm_impl(const hs_gemm_params* p, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 struct GemmGroup {
     int combo = -1;       // 2 / 5: 64x64 tiles (gemm_bf16_grouped_kernel); 0: K-contiguous operands, 256x128 tiles, row sums (_big_kernel)
+    int cfg = -1;         // combo 0: CFG_256x128 (generic body) or CFG_P8_256 (phase-pipelined body, 256x256 tiles)
+    bool rs = false;      // some problem of a CFG_P8_256 group wants row sums
     std::vector<GemmArgs> items;
     std::vector<int> first;
     int total = 0, ticket_off = 0;
@@ -619,6 +621,8 @@ GemmGroup* gemm_group_open(hipStream_t s, long long slot) {
     GemmGroup*& g = groups[std::make_tuple(dev, s, slot)];
     if (!g) g = new GemmGroup();
     g->combo = -1;
+    g->cfg = -1;
+    g->rs = false;
     g->items.clear();
     g->first.clear();
     g->total = 0;
@@ -631,7 +635,7 @@ int gemm_group_flush(GemmGroup* g, hipStream_t s) {
     const int n = (int)g->items.size();
     constexpr size_t kHead = 512;                                   // first_wg[0..64] and padding
     const size_t bytes = kHead + (size_t)n * sizeof(GemmArgs);
-    if (g->combo == 0 && n <= 4) {          // small groups of the big-tile kind travel in the kernel arguments
+    if (g->combo == 0 && n <= 4 && g->cfg != CFG_P8_256) {          // small groups of the big-tile kind travel in the kernel arguments
         ProfRec rec;
         const bool timed = prof_begin(s, g->flops, 0, rec);
         const int st = launch_bf16_grouped_big4(g->items.data(), g->first.data(), n, g->total, s);
@@ -642,6 +646,8 @@ int gemm_group_flush(GemmGroup* g, hipStream_t s) {
             prof_end(s, rec);
         }
         g->combo = -1;
+        g->cfg = -1;
+        g->rs = false;
         g->items.clear();
         g->first.clear();
         g->total = 0;
@@ -676,16 +682,19 @@ int gemm_group_flush(GemmGroup* g, hipStream_t s) {
     ProfRec rec;
     const bool timed = prof_begin(s, g->flops, g->combo == 5 ? 1 : 0, rec);
     const int st = g->combo == 5   ? launch_bf16_grouped_conv(5, (const GemmArgs*)(g->dev + kHead), (const int*)g->dev, n, g->total, s)
+                   : (g->combo == 0 && g->cfg == CFG_P8_256) ? launch_bf16_p8_grouped((const GemmArgs*)(g->dev + kHead), (const int*)g->dev, n, g->total, g->rs, s)
                    : g->combo == 0 ? launch_bf16_grouped_big(0, (const GemmArgs*)(g->dev + kHead), (const int*)g->dev, n, g->total, s)
                                    : launch_bf16_grouped_plain(2, (const GemmArgs*)(g->dev + kHead), (const int*)g->dev, n, g->total, s);
     if (timed) {
         rec.M = n; rec.N = 0; rec.K = 0; rec.combo = g->combo == 5 ? 7 : g->combo == 0 ? 8 : 6;
-        rec.cfg = g->combo == 0 ? CFG_256x128 : CFG_64x64; rec.split = 0; rec.batch = 1;
+        rec.cfg = g->combo == 0 ? (g->cfg == CFG_P8_256 ? CFG_P8_256 : CFG_256x128) : CFG_64x64; rec.split = 0; rec.batch = 1;
         rec.conv_r = 0; rec.conv_stride = 0;
         rec.bytes = g->bytes;
         prof_end(s, rec);
     }
     g->combo = -1;
+    g->cfg = -1;
+    g->rs = false;
     g->items.clear();
     g->first.clear();
     g->total = 0;
@@ -698,17 +707,29 @@ int gemm_group_add(GemmGroup* g, const hs_gemm_params* p, hipStream_t s) {
     if (!g) return gemm_impl(p, s);
     Prepared q;
     const bool big = p->a_kind == HS_A_KC && p->b_kind == HS_B_KC;       // K-contiguous weight gradients: 256x128 tiles
-    HS_PROPAGATE(gemm_prepare(p, s, q, big ? CFG_256x128 : -1));
-    const bool ok = big ? (q.bf16 && q.cfg == CFG_256x128 && q.combo == 0 && q.batch == 1 && q.split == 1 && !q.a.stamps && !q.a.colstats)
+    // ... or, when every tile is a full 256 x 256 one and the group is a deep-K one (K >= 2048: the K walk has to amortise the
+    // one-tile-per-CU body's ramp), the phase-pipelined body.  HAMSPINE_P8_WGRAD=0 keeps the generic 256x128 tiles.
+    static const bool p8w = [] { const char* e = getenv("HAMSPINE_P8_WGRAD"); return !(e && e[0] == '0'); }();
+    const bool want_p8 = big && p8w && p->dtype == HS_BF16 && p->M % 256 == 0 && p->N % 256 == 0 && p->K % 64 == 0 && p->K >= 2048 &&
+                         (p->batch <= 1) && p->split_k <= 1 && g_dbg_cfg < 0 && (g->items.empty() || g->combo != 0 || g->cfg == CFG_P8_256);
+    HS_PROPAGATE(gemm_prepare(p, s, q, big ? (want_p8 ? CFG_P8_256 : CFG_256x128) : -1));
+    if (want_p8 && !(p8_epilogue_supported(q.a) && !q.a.colstats && !q.a.bnb_partials && (long long)p->M * p->lda * 2 < 0x7fffff00ll &&
+                     (long long)p->N * p->ldb * 2 < 0x7fffff00ll))
+        HS_PROPAGATE(gemm_prepare(p, s, q, CFG_256x128));
+    const bool ok = big ? (q.bf16 && (q.cfg == CFG_256x128 || q.cfg == CFG_P8_256) && q.combo == 0 && q.batch == 1 && q.split == 1 && !q.a.stamps && !q.a.colstats)
                         : (q.bf16 && q.cfg == CFG_64x64 && (q.combo == 2 || q.combo == 5) && q.batch == 1 && !q.a.stamps &&
                            (q.split == 1 || q.a.tickets != nullptr) && !q.a.rowsum[0] && !q.a.colstats);
     if (!ok) return gemm_impl(p, s);
     const long long ngroups = q.split > 1 ? (q.split + kSplitGroup - 1) / kSplitGroup : 0;
     const long long need = q.split > 1 ? (long long)q.a.tiles_m * q.a.tiles_n * (1 + (ngroups > 1 ? ngroups : 0)) : 0;
-    if (!g->items.empty() && (g->combo != q.combo || (int)g->items.size() >= kGroupMax || g->ticket_off + need > kTicketPool))
+    if (!g->items.empty() && (g->combo != q.combo || (big && g->cfg != q.cfg) || (int)g->items.size() >= kGroupMax || g->ticket_off + need > kTicketPool))
         HS_PROPAGATE(gemm_group_flush(g, s));
     if (need > kTicketPool) return gemm_impl(p, s);
     g->combo = q.combo;
+    if (big) {
+        g->cfg = q.cfg;
+        g->rs = g->rs || q.a.rowsum[0] != nullptr;
+    }
     if (q.split > 1) q.a.tickets += g->ticket_off;
     g->ticket_off += (int)need;
     g->first.push_back(g->total);

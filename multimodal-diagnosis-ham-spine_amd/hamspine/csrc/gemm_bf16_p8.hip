@@ -12,6 +12,20 @@ static int launch_p8(K kernel, int lds, int threads, const GemmArgs& a, dim3 gri
     HS_LAUNCH_CHECK();
     return HS_OK;
 }
+int launch_bf16_p8_grouped(const GemmArgs* list, const int* first_wg, int n, int total_wgs, bool rs, hipStream_t s) {
+    constexpr int lds = 128 * 1024;
+    if (rs) {
+        auto kernel = gemm_bf16_p8_grouped_kernel<true>;
+        if (lds_attr_needed((const void*)kernel)) HS_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(kernel, dim3(total_wgs), dim3(512), lds, s, list, first_wg, n);
+    } else {
+        auto kernel = gemm_bf16_p8_grouped_kernel<false>;
+        if (lds_attr_needed((const void*)kernel)) HS_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(kernel, dim3(total_wgs), dim3(512), lds, s, list, first_wg, n);
+    }
+    HS_LAUNCH_CHECK();
+    return HS_OK;
+}
 int launch_bf16_p8(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
     const bool rs = a.rowsum[0] != nullptr;
     switch (cfg) {

@@ -9,6 +9,7 @@ enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_STEM = 3, CFG_256x128
 int launch_bf16_plain(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s);
 int launch_bf16_conv(int cfg, int combo, const GemmArgs& a, dim3 grid, hipStream_t s);
 int launch_bf16_p8(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s);
+int launch_bf16_p8_grouped(const GemmArgs* list, const int* first_wg, int n, int total_wgs, bool rs, hipStream_t s);   // 256x256 p8 tiles
 int launch_bf16_conv3(const GemmArgs& a, int fm, dim3 grid, hipStream_t s);   // C3: 3x3 stride-1 halo-patch kernel (conv3.hip)
 int conv3_lds_bytes(int fm);
 // one grid for n <= 64 problems of one operand layout, 64x64 tiles (gemm_bf16_grouped_kernel); tables in device memory

@@ -37,7 +37,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // second workgroup is the partner).
 // DIAG (measurement build of the kernel, launched only when hs_gemm_debug_stamps armed a buffer): waves 0 and NW/2 stamp the
 // shader clock around every segment of ONE K tile in the middle of the walk: 17 stamps per wave at a.stamps[(bx * 2 + group) * 20].
-template <int BM, int BN, int WGM, int WGN, bool RS, bool STAG, bool DIAG = false>
+// TAG: unused by the code.  Two __global__ templates that instantiate the SAME specialization of this body fail on hipcc's host
+// pass ("no matching function ... substitution failure", ROCm 7.2); a distinct TAG gives the second kernel its own specialization.
+template <int BM, int BN, int WGM, int WGN, bool RS, bool STAG, bool DIAG = false, int TAG = 0>
 __device__ __forceinline__ void gemm_bf16_p8_body(const GemmArgs& a, const int bx) {
     typedef bf16_t T;
     constexpr int BK = 64, NW = WGM * WGN;
@@ -343,6 +345,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_256_kernel(const GemmArgs a)
     gemm_bf16_p8_body<256, 256, 2, 4, RS, true>(a, blockIdx.x);
 }
 __global__ __launch_bounds__(512) void gemm_bf16_p8_256_diag_kernel(const GemmArgs a);   // measurement build (gemm_bf16_p8.hip)
+// Grouped: the workgroups of up to 64 independent nt GEMMs (256 x 256 tiles) in ONE grid, problem table in device memory --
+// the K-contiguous weight gradients of TWO BertLayers (8 GEMMs, K = the 4096 tokens: 216 tiles, one per CU, 64 K tiles each:
+// the steady state this body is built for).  first_wg[i] = first workgroup of problem i, first_wg[n] = grid size.
+template <bool RS>
+__global__ __launch_bounds__(512) void gemm_bf16_p8_grouped_kernel(const GemmArgs* __restrict__ list, const int* __restrict__ first_wg, int n) {
+    const int bid = blockIdx.x, lane = threadIdx.x & 63;
+    const int lo = lane < n ? first_wg[lane] : 0x7fffffff;
+    const int p = __builtin_amdgcn_readfirstlane(__popcll(__ballot(lo <= bid)) - 1);
+    const int local = bid - __builtin_amdgcn_readfirstlane(first_wg[p]);
+    gemm_bf16_p8_body<256, 256, 2, 4, RS, true, false, 1>(list[p], local);   // (TAG: its own specialization -- see the note at the body)
+}
 // 256 x 128 tile, 8 waves (4 x 2, 64 x 64 per wave), 96 KiB: the shapes whose N gives too few 256-wide tiles
 template <bool RS>
 __global__ __launch_bounds__(512) void gemm_bf16_p8_256x128_kernel(const GemmArgs a) {
