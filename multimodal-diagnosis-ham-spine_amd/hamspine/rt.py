@@ -62,7 +62,10 @@ def tower_stream(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     s = _tower_streams.get(idx)
     if s is None:
-        s = torch.cuda.Stream(device=idx)
+        import os
+        # HAMSPINE_TOWER_PRIORITY: queue priority of the text tower's stream (-1 = high: its workgroups are dispatched ahead of
+        # the image tower's when both streams have work pending)
+        s = torch.cuda.Stream(device=idx, priority=int(os.environ.get("HAMSPINE_TOWER_PRIORITY", "0")))
         _tower_streams[idx] = s
     return s
 
