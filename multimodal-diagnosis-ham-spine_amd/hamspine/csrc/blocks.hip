@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 #include <stdlib.h>
 #include "hs_common.h"
 #include "pw_stream.h"
@@ -1653,9 +1654,13 @@ static int resnet_bwd_run(Run& r, const hs_resnet_desc& d, const void* const* dy
     // (1x1 / spatial filters) behind the data-gradient chain; the blocks' scratch is then kept to the end (HAMSPINE_GROUPED_WGRAD=0:
     // one launch per convolution, scratch released per block)
     r.defer_wgrad = dt == HS_BF16 && grouped_wgrad_enabled() && !overlap_enabled();
+    static const bool staged_on = [] { const char* e = getenv("HAMSPINE_STAGED_WGRAD"); return !(e && e[0] == '0'); }();
+    const bool staged = r.defer_wgrad && !r.plan && g_ms.n > 0 && staged_on;
+    int seg = 0;
+    std::vector<const void*> seg_ptrs;
     if (r.defer_wgrad && !r.plan) {
-        r.grp_pw = gemm_group_open(r.s, 0);
-        r.grp_conv = gemm_group_open(r.s, 1);
+        r.grp_pw = gemm_group_open(r.s, staged ? 8 : 0);
+        r.grp_conv = gemm_group_open(r.s, staged ? 9 : 1);
         HS_REQUIRE(r.grp_pw && r.grp_conv, "resnet_bwd: cannot set up the grouped weight-gradient launches");
     }
     // Block-final BatchNorm sums across the block boundary: block i + 1's stage-0 data-gradient GEMM writes the gradient of
@@ -1727,6 +1732,30 @@ static int resnet_bwd_run(Run& r, const hs_resnet_desc& d, const void* const* dy
         own_next = OwnSums{};
         if (nb && xs_rows > 0) own_next = OwnSums{xs_buf[i & 1], xs_bytes, xs_rows, xs_done};
         if (!r.defer_wgrad) r.ws.release(wm);
+        // Under a data-parallel wrapper (gradient milestones registered) the deferred weight gradients leave per STAGE: when the
+        // first block of a stage (the one with the downsample branch) is done, the stage's two grouped grids run and the
+        // events of the buckets that end in this stage are recorded -- layer4 holds 60 % of a ResNet50's parameters, and its
+        // exchange then has the rest of the backward to hide in instead of starting behind the tower's last kernel.
+        // Without a wrapper (N = 1) the two grids at the end stay as they are.
+        if (staged) {
+            const hs_resblock_desc& bd = d.blocks[i];
+            for (int k = 0; k < bd.n_main; ++k) {
+                seg_ptrs.push_back(bd.main[k].dw); seg_ptrs.push_back(bd.main[k].dgamma); seg_ptrs.push_back(bd.main[k].dbeta);
+            }
+            if (bd.has_ds) {
+                seg_ptrs.push_back(bd.ds.dw); seg_ptrs.push_back(bd.ds.dgamma); seg_ptrs.push_back(bd.ds.dbeta);
+            }
+            if (bd.has_ds && i > 0) {
+                HS_PROPAGATE(gemm_group_flush(r.grp_pw, r.s));
+                HS_PROPAGATE(gemm_group_flush(r.grp_conv, r.s));
+                HS_PROPAGATE(milestones_hit(r, seg_ptrs.data(), (int)seg_ptrs.size()));
+                seg_ptrs.clear();
+                ++seg;
+                r.grp_pw = gemm_group_open(r.s, 8 + 2 * seg);
+                r.grp_conv = gemm_group_open(r.s, 9 + 2 * seg);
+                HS_REQUIRE(r.grp_pw && r.grp_conv, "resnet_bwd: cannot set up the grouped weight-gradient launches");
+            }
+        }
         dy = dx;
         cur ^= 1;
     }

@@ -59,7 +59,8 @@ def _with_milestones(ent, params, call):
     """run `call()` (one hs_*_bwd) with the data-parallel wrappers' bucket milestones registered: each gets the event of
     every bucket recorded at the point of this stream where that bucket's last gradient has been enqueued"""
     stream = torch.cuda.current_stream()
-    asked = rt.grad_milestones(params, stream) if ent.store is None else []
+    # (parameters that get no gradient from this backward are passed as None: the wrapper books only what is produced)
+    asked = rt.grad_milestones([p if ent.grad_ptrs[i] else None for i, p in enumerate(params)], stream) if ent.store is None else []
     flat = [(ent.grad_ptrs[i], ev) for _, ms in asked for i, ev, _ in ms if ent.grad_ptrs[i]]
     lib = L.lib()
     if flat:

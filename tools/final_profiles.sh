@@ -2,7 +2,8 @@
 # Regenerates the committed round profiles on the GPU box (run from the repo root):
 #   bash tools/final_profiles.sh roundN
 # kernel traces of bench.py with and without stream overlap -> profiles/<round>_final_{isolated,overlapped}_*;
-# PMC passes (FETCH_SIZE / WRITE_SIZE, separate) -> profiles/<round>_pmc_traffic.json
+# PMC passes (FETCH_SIZE / WRITE_SIZE, separate; towers un-overlapped like bench.py's roofline leg, so that the counted
+# dispatches come in the order of the launch log that names their classes) -> profiles/<round>_pmc_traffic.json
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-round3}
@@ -12,8 +13,8 @@ mkdir -p $OUT $PROF
 cd /tmp && export TMPDIR=/tmp
 HAMSPINE_OVERLAP=0 HAMSPINE_TOWER_OVERLAP=0 timeout -k 10 400 rocprofv3 --kernel-trace -d $OUT/iso -o iso -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32 --no-ddp-config > $OUT/iso.log 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace -d $OUT/ovl -o ovl -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32 --no-ddp-config > $OUT/ovl.log 2>&1
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-f32 --no-ddp-config --gemm-log $OUT/launches_pmc.csv > $OUT/fetch.log 2>&1
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-f32 --no-ddp-config > $OUT/write.log 2>&1
+HAMSPINE_OVERLAP=0 HAMSPINE_TOWER_OVERLAP=0 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-f32 --no-ddp-config --gemm-log $OUT/launches_pmc.csv > $OUT/fetch.log 2>&1
+HAMSPINE_OVERLAP=0 HAMSPINE_TOWER_OVERLAP=0 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-f32 --no-ddp-config > $OUT/write.log 2>&1
 cd $R
 python3 tools/profile_summary.py $OUT/iso/iso_results.db 0 $PROF/${TAG}_final_isolated \
   "rocprofv3 --kernel-trace of \`HAMSPINE_OVERLAP=0 HAMSPINE_TOWER_OVERLAP=0 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32\` (${TAG}, final)" \

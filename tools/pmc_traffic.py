@@ -19,7 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-FAMILY = "gemm_bf16_"        # gemm_bf16_kernel<...>, _w3, _grouped, _bnf, _bns, _p8_* ...
+FAMILY = ("gemm_bf16_", "conv3_bf16_")   # + the 3x3 halo-patch kernel (csrc/conv3.hip): same MFMA family, other staging
 
 
 def build_id():
@@ -40,7 +40,7 @@ def family_rows(path):
         rows = db.execute("select name, counter_value, dispatch_id from pmc_events order by dispatch_id").fetchall()
     except sqlite3.OperationalError:
         rows = [(n, v, i) for i, (n, v) in enumerate(db.execute("select name, counter_value from pmc_events").fetchall())]
-    return [(n, v) for n, v, _ in rows if FAMILY in n], sum(v for _, v, _ in rows), len(rows)
+    return [(n, v) for n, v, _ in rows if any(f in n for f in FAMILY)], sum(v for _, v, _ in rows), len(rows)
 
 
 def classes_of(csv_path):
@@ -75,12 +75,12 @@ def main(fetch_db, write_db, out, launches=None):
     fetch_b = 2.0 * sum(v for _, v in f_rows) * 1024.0
     write_b = sum(v for _, v in w_rows) * 1024.0
     res = {
-        "kernel_family": "gemm_bf16_* (tiled / grouped / phase-pipelined bodies)", "launches": n,
+        "kernel_family": "gemm_bf16_* (tiled / grouped / phase-pipelined bodies) + conv3_bf16_kernel", "launches": n,
         "fetch_bytes_per_launch": fetch_b / n, "write_bytes_per_launch": write_b / n,
         "traffic_bytes_per_launch": (fetch_b + write_b) / n,
         "all_kernels_bytes_total": 2.0 * f_all * 1024.0 + w_all * 1024.0, "all_kernels_launches": n_all,
         "build_id": build_id(),
-        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `bench.py --steps 3 --warmup 2`; "
+        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `HAMSPINE_OVERLAP=0 HAMSPINE_TOWER_OVERLAP=0 bench.py --steps 3 --warmup 2`; "
                   "KB -> bytes, FETCH_SIZE doubled (gfx950 128-B requests tallied at 64 B)",
     }
     if launches:

@@ -8,7 +8,7 @@ import collections
 import sqlite3
 import sys
 
-FAMILY = "gemm_bf16_"        # gemm_bf16_kernel<...>, gemm_bf16_kernel_w3<...>, gemm_bf16_grouped_kernel<...>
+FAMILY = ("gemm_bf16_", "conv3_bf16_")   # + the 3x3 halo-patch kernel (csrc/conv3.hip): same MFMA family, other staging
 TFLOP_PER_STEP = 2.897       # bench.py: algorithmic_tflop_per_step of the family (strided dgrads count executed taps)
 PEAK = 2500.0
 
@@ -29,8 +29,8 @@ def main(db_path, steps, out, title, extra=""):
         f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n")
         for name, (c, t) in order:
             f.write(f"\"{name}\",{c},{t},{t / c:.1f},{100.0 * t / total:.3f}\n")
-    fam_c = sum(c for n, (c, t) in by.items() if FAMILY in n)
-    fam_t = sum(t for n, (c, t) in by.items() if FAMILY in n)
+    fam_c = sum(c for n, (c, t) in by.items() if any(f in n for f in FAMILY))
+    fam_t = sum(t for n, (c, t) in by.items() if any(f in n for f in FAMILY))
     ms = fam_t / steps / 1e6
     tf = TFLOP_PER_STEP / (ms * 1e-3)
     with open(out + "_summary.md", "w") as f:
@@ -39,7 +39,7 @@ def main(db_path, steps, out, title, extra=""):
             f.write(extra.strip() + "\n\n")
         f.write(f"* steps in the trace: {steps}; kernel time per step (sum of durations): **{total / steps / 1e6:.2f} ms**, "
                 f"{len(rows) / steps:.0f} launches/step\n")
-        f.write(f"* dominant kernel family `gemm_bf16_kernel<...>` (+ `_w3`, `_grouped`): **{ms:.2f} ms/step**, {fam_c / steps:.0f} launches/step, "
+        f.write(f"* dominant kernel family `gemm_bf16_*` (tiled / grouped / phase-pipelined bodies) + `conv3_bf16_kernel`: **{ms:.2f} ms/step**, {fam_c / steps:.0f} launches/step, "
                 f"average launch {fam_t / fam_c / 1e3:.1f} us -> {TFLOP_PER_STEP:.2f} TFLOP / {ms:.2f} ms = **{tf:.0f} TFLOP/s** "
                 f"({100.0 * tf / PEAK:.1f} % of the 2.5 PFLOP/s dense bf16 MFMA peak)\n\n")
         f.write("| ms/step | % | calls/step | avg us | kernel |\n|---|---|---|---|---|\n")
