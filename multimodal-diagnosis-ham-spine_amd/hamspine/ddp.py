@@ -140,6 +140,8 @@ class DataParallel(nn.Module):
         self._covered = set()                         # ids of parameters whose gradients a tower milestone covers (this step)
         self._bulk_done = set()                       # ... and that were booked in bulk when the tower reported its events
         self._bulk_next = None
+        self._ms_cache = {}                           # per tower parameter list: (list, bucket-ending members, bulk list, covered ids)
+        self._unused_epoch = 0                        # bumped whenever a parameter's unused flag changes
         self.stats = {"launched_in_backward": 0, "launched_in_finish": 0}   # how many bucket collectives overlapped backward
         backend = dist.get_backend(self.pg) if dist.is_initialized() else None
         nccl = backend == "nccl"                      # AVG exists in RCCL only; gloo sums, then / world
@@ -179,24 +181,33 @@ class DataParallel(nn.Module):
         backward walks the layers from the top down).  Returns [(index into params, event handle, key)]: for every bucket
         holding some of these parameters, the member whose gradient is enqueued LAST and the event the executor records
         right after it."""
-        first = {}
-        bulk = []
-        for i, p in enumerate(params):
-            w = None if p is None else self._where.get(p)
-            if w is None:
-                continue
-            self._covered.add(id(p))                  # its position in the stream is covered by a milestone, not by a hook event
-            b, k = w
-            if b.unused[k]:
-                continue
-            bulk.append((b, k, id(p)))
-            if id(b) in first:
-                continue
-            first[id(b)] = (i, b)
+        # what does not change from step to step (which bucket ends where, who is booked) is worked out once per tower and
+        # unused-set: this runs on the autograd thread in front of the tower's one C call
+        ckey = (id(params), len(params), sum(1 for p in params if p is None), self._unused_epoch)
+        ent = self._ms_cache.get(ckey)
+        if ent is None or ent[0] is not params:
+            first = {}
+            bulk = []
+            cov = []
+            for i, p in enumerate(params):
+                w = None if p is None else self._where.get(p)
+                if w is None:
+                    continue
+                cov.append(id(p))                     # its position in the stream is covered by a milestone, not by a hook event
+                b, k = w
+                if b.unused[k]:
+                    continue
+                bulk.append((b, k, id(p)))
+                if id(b) in first:
+                    continue
+                first[id(b)] = (i, b)
+            ent = self._ms_cache[ckey] = (params, list(first.values()), bulk, cov)
+        _, firsts, bulk, cov = ent
+        self._covered.update(cov)
         self._bulk_next = (stream, bulk)              # booked in one go when the tower reports its events (_milestones_recorded)
         out = []
         sid = stream.cuda_stream
-        for i, b in first.values():
+        for i, b in firsts:
             ev = self._event(b, sid)
             ev.record(stream)                         # creates the HIP event (torch creates it lazily); re-recorded by the executor
             out.append((i, ev.cuda_event, (b, sid, ev)))
@@ -251,6 +262,7 @@ class DataParallel(nn.Module):
         if b.unused[i]:                                      # the used set grew: count it from now on (re-learn)
             b.unused[i] = False
             b.need += 1
+            self._unused_epoch += 1
         view = b.views[i]
         if p.grad.data_ptr() != view.data_ptr():             # gradient produced outside the arena: copy once
             view.copy_(p.grad)
@@ -359,6 +371,7 @@ class DataParallel(nn.Module):
         for b in self.buckets:
             b.need = sum(1 for u in b.unused if not u)
         self._learnt_unused = True
+        self._unused_epoch += 1
 
     def finish(self):
         """Launch the buckets that did not complete during backward (unused parameters) and wait for all exchanges.

@@ -60,7 +60,10 @@ def _with_milestones(ent, params, call):
     every bucket recorded at the point of this stream where that bucket's last gradient has been enqueued"""
     stream = torch.cuda.current_stream()
     # (parameters that get no gradient from this backward are passed as None: the wrapper books only what is produced)
-    asked = rt.grad_milestones([p if ent.grad_ptrs[i] else None for i, p in enumerate(params)], stream) if ent.store is None else []
+    mp = getattr(ent, "_ms_params", None)              # (the same list object every step: the wrapper caches its bookkeeping on it)
+    if mp is None or mp[0] is not ent.grad_ptrs:
+        mp = ent._ms_params = (ent.grad_ptrs, [p if ent.grad_ptrs[i] else None for i, p in enumerate(params)])
+    asked = rt.grad_milestones(mp[1], stream) if ent.store is None else []
     flat = [(ent.grad_ptrs[i], ev) for _, ms in asked for i, ev, _ in ms if ent.grad_ptrs[i]]
     lib = L.lib()
     if flat:
