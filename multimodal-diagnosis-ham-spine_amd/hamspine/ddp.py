@@ -136,7 +136,16 @@ class DataParallel(nn.Module):
         self._callback_queued = False
         self._dirty = False
         self._learnt_unused = False
-        self._next = 0                                # index of the next bucket to launch (launches are in order)
+        self._next = 0                                # position in _launch_order of the next bucket to launch (launches are in order)
+        # Launch order: bucket index order until it is learnt.  On the third step every bucket's events carry timestamps; the
+        # buckets are then sorted by the device time at which their last gradient was final (rank 0's order, broadcast), so
+        # that on the one exchange stream no bucket waits behind one that becomes ready later -- index order does that
+        # whenever the module's parameter order is not its backward's completion order (two towers on two streams; the image
+        # tower's layer4 is final long before the text tower's embeddings, whatever the order of the submodules).
+        self._launch_order = list(range(len(self.buckets)))
+        self._order_learnt = not (self.on_gpu and self.collective)   # (CPU / gloo runs keep index order: no device timeline to learn from)
+        self._steps = 0
+        self._ref_ev = None
         self._covered = set()                         # ids of parameters whose gradients a tower milestone covers (this step)
         self._bulk_done = set()                       # ... and that were booked in bulk when the tower reported its events
         self._bulk_next = None
@@ -172,8 +181,15 @@ class DataParallel(nn.Module):
 
     # ---- milestones: called by hamspine.tower around a whole-tower backward --------------------------------------------
     def _event(self, b, sid):
+        if not self._order_learnt:                    # timestamps wanted: fresh timing events (the pool holds plain ones)
+            return torch.cuda.Event(enable_timing=True)
         pool = b.spare.setdefault(sid, [])
         return pool.pop() if pool else torch.cuda.Event()
+
+    def _mark_step_start(self):
+        if not self._order_learnt and self._ref_ev is None and self.on_gpu:
+            self._ref_ev = torch.cuda.Event(enable_timing=True)
+            self._ref_ev.record(torch.cuda.current_stream(self.device))
 
     def _milestones(self, params, stream):
         """`params`: a tower's parameters in the order its backward FINISHES their gradients last-to-first reversed, i.e.
@@ -183,6 +199,7 @@ class DataParallel(nn.Module):
         right after it."""
         # what does not change from step to step (which bucket ends where, who is booked) is worked out once per tower and
         # unused-set: this runs on the autograd thread in front of the tower's one C call
+        self._mark_step_start()
         ckey = (id(params), len(params), sum(1 for p in params if p is None), self._unused_epoch)
         ent = self._ms_cache.get(ckey)
         if ent is None or ent[0] is not params:
@@ -249,6 +266,7 @@ class DataParallel(nn.Module):
         behind the node that produced the gradient)"""
         if id(p) in self._bulk_done:                         # a tower gradient, already booked with its milestone
             return
+        self._mark_step_start()
         b, i = self._where[p]
         if b.launched:
             if b.unused[i]:
@@ -295,9 +313,9 @@ class DataParallel(nn.Module):
         return self.static_unused or b.need == len(b.params)
 
     def _launch_ready(self, in_backward):
-        """launch, in index order, every bucket that is complete (in finish(): every remaining bucket)"""
+        """launch, in the agreed order, every bucket that is complete (in finish(): every remaining bucket)"""
         while self._next < len(self.buckets):
-            b = self.buckets[self._next]
+            b = self.buckets[self._launch_order[self._next]]
             if in_backward:
                 # before the unused set is known a bucket is complete when ALL its parameters have arrived
                 ok = self._complete(b) if self._learnt_unused else b.ready == len(b.params)
@@ -373,6 +391,32 @@ class DataParallel(nn.Module):
         self._learnt_unused = True
         self._unused_epoch += 1
 
+    def _learn_order(self):
+        """third step: sort the buckets by the device time at which their last gradient was final (rank 0 decides)"""
+        torch.cuda.synchronize(self.device)
+        ref = self._ref_ev
+        times = []
+        for k, b in enumerate(self.buckets):
+            t = None
+            evs = list(b.events.values()) + [b.hook_events[sid] for sid in b.hook_sids if sid in b.hook_events]
+            for ev in evs:
+                try:
+                    dt = ref.elapsed_time(ev) if ref is not None else 0.0
+                except Exception:          # a plain event left from before the learning steps: no timestamp
+                    dt = None
+                if dt is not None:
+                    t = dt if t is None else max(t, dt)
+            times.append(float("inf") if t is None else t)
+        order = sorted(range(len(self.buckets)), key=lambda k: (times[k], k))
+        if self.world > 1 and self.collective:
+            o = torch.tensor(order, dtype=torch.int32, device=self.device if dist.get_backend(self.pg) == "nccl" else "cpu")
+            dist.broadcast(o, src=0, group=self.pg)
+            order = [int(v) for v in o.cpu().tolist()]
+        self._launch_order = order
+        self._order_learnt = True
+        self.stats["launch_order"] = order
+        self.stats["ready_ms"] = [round(t, 3) if t != float("inf") else None for t in times]
+
     def finish(self):
         """Launch the buckets that did not complete during backward (unused parameters) and wait for all exchanges.
         Called by the autograd engine at the end of backward; safe to call again before optimizer.step()."""
@@ -392,6 +436,11 @@ class DataParallel(nn.Module):
         first = not self._learnt_unused
         if first:
             self._learn()
+        self._steps += 1
+        drop_timed = False
+        if not self._order_learnt and self._steps >= 3:
+            self._learn_order()
+            drop_timed = True
         for b in self.buckets:
             for i, p in enumerate(b.params):
                 if not b.have[i] and p.grad is not None and p.grad.data_ptr() == b.views[i].data_ptr():
@@ -404,9 +453,14 @@ class DataParallel(nn.Module):
             for sid, ev in b.events.items():
                 b.spare.setdefault(sid, []).append(ev)
             b.events = {}
+        if drop_timed:                                       # the timestamped events of the learning steps are not reused
+            for b in self.buckets:
+                b.spare = {}
+                b.hook_events = {}
         self._covered = set()
         self._bulk_done = set()
         self._bulk_next = None
+        self._ref_ev = None
         self._next = 0
 
     def detach(self):
