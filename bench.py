@@ -384,7 +384,7 @@ def ddp_config_leg(net, fwd_loss, make_opt, device, batch, steps):
                 ddp.finish()
                 opt.step()
                 return loss
-            for _ in range(3):
+            for _ in range(6):                       # (the wrapper learns its unused set on step 1 and its launch order on step 3)
                 step()
             torch.cuda.synchronize()
             t0 = time.perf_counter()

@@ -129,6 +129,10 @@ class DataParallel(nn.Module):
                 if self.zero_copy:
                     rt.grad_arena_register(p, b.views[i])
                 self._hook_handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        # (Normal priority on purpose.  HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES = 4) and a queue whose
+        # head is a pending event wait holds back every stream sharing it; moving this stream and RCCL's internal one
+        # (TORCH_NCCL_HIGH_PRIORITY=1) to the high-priority queues was measured: the one-rank exchange kernels then starve
+        # the towers, 25 ms per step.  GPU_MAX_HW_QUEUES=8: 16.7 ms.  profiles/round3_ddp_queue_experiments.txt)
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         # the text tower's gradients are produced on its own stream while the hooked AccumulateGrad nodes were created on
         # the ambient one; autograd orders the two correctly and says so on every backward
@@ -143,7 +147,13 @@ class DataParallel(nn.Module):
         # whenever the module's parameter order is not its backward's completion order (two towers on two streams; the image
         # tower's layer4 is final long before the text tower's embeddings, whatever the order of the submodules).
         self._launch_order = list(range(len(self.buckets)))
-        self._order_learnt = not (self.on_gpu and self.collective)   # (CPU / gloo runs keep index order: no device timeline to learn from)
+        # OFF unless HAMSPINE_DDP_LEARN_ORDER=1 (CPU / gloo runs: always index order).  Measured on one rank: C3's exposed tail
+        # drops from 0.75 to 0.09 ms, C2 is unchanged -- but with the learnt order the first ResNet bucket's exchange is issued
+        # between the two towers' backward calls, its event wait reaches a hardware queue early, and when the text tower's
+        # stream shares that queue (it did after ten wrapper-less training steps, it did not in a fresh process) BERT's
+        # backward starts 1-2 ms late: 13.1 vs 12.1 ms per step.  Index order has the same exposure in principle and has not
+        # shown it in any context measured.
+        self._order_learnt = not (self.on_gpu and self.collective) or os.environ.get("HAMSPINE_DDP_LEARN_ORDER", "0") != "1"
         self._steps = 0
         self._ref_ev = None
         self._covered = set()                         # ids of parameters whose gradients a tower milestone covers (this step)
