@@ -313,7 +313,7 @@ def gpu_leg(args, rank, world, local_rank):
     roofline = {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
-        "kernel": "gemm_bf16_kernel<BM,BN,BK,A,B> (bf16 MFMA GEMM + implicit-GEMM conv core)",
+        "kernel": "gemm_bf16_* (bf16 MFMA GEMM / implicit-GEMM convolution family: tiled, grouped and phase-pipelined bodies, + conv3_bf16_kernel)",
         "launches_per_step": fam_launches // prof_steps,
         "avg_launch_us": round(fam_ms * 1e3 / max(fam_launches, 1), 2),
         "kernel_ms_per_step": round(fam_ms / prof_steps, 3),
