@@ -783,14 +783,14 @@ __global__ __launch_bounds__(256) void transpose_bf16_multi_kernel(const Transpo
 // Replaces nn.CrossEntropyLoss(weight, label_smoothing=0.02) (reference scripts/train.py:240,252-254)
 // and F.cross_entropy (mibf_net/model_resnet.py:88-90).  One block, rows strided over waves.
 // ============================================================================================
-__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+__global__ __launch_bounds__(1024) void ce_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
                                                  const float* __restrict__ weight, float smoothing, int B, int C,
                                                  float* __restrict__ loss_out, float* __restrict__ dlogits,
                                                  float* __restrict__ row_loss) {
-    __shared__ float s_num[4], s_den[4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ float s_num[16], s_den[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;      // 4..16 waves: a wave per 1-2 rows of a batch of 32
     float num = 0.f, den = 0.f;
-    for (int r = wv; r < B; r += 4) {
+    for (int r = wv; r < B; r += nwv) {
         const float* z = logits + (long long)r * C;
         float mx = -INFINITY;
         for (int c = lane; c < C; c += 64) mx = fmaxf(mx, z[c]);
@@ -813,11 +813,14 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
         s_den[wv] = den;
     }
     __syncthreads();
-    const float tn = s_num[0] + s_num[1] + s_num[2] + s_num[3];
-    const float td = s_den[0] + s_den[1] + s_den[2] + s_den[3];
+    float tn = 0.f, td = 0.f;
+    for (int w = 0; w < nwv; ++w) {
+        tn += s_num[w];
+        td += s_den[w];
+    }
     if (threadIdx.x == 0) loss_out[0] = tn / td;
     if (!dlogits) return;
-    for (int r = wv; r < B; r += 4) {
+    for (int r = wv; r < B; r += nwv) {
         const float* z = logits + (long long)r * C;
         float mx = -INFINITY;
         for (int c = lane; c < C; c += 64) mx = fmaxf(mx, z[c]);
@@ -980,6 +983,7 @@ static int mean_tokens_bwd_t(const void* dy, void* dx, int B, int Nt, int H, int
 
 // row groups (grid.y): enough blocks to cover the chip also when the matrix is narrow (one or two blocks along x)
 static inline int colsum_gy(long long M, int N) {
+    if (M <= 64) return 1;             // a head's batch of rows: one row group, and its partial row IS the result (colsum_t)
     const long long cap = std::max<long long>(64, 1024 / ceil_div(N, 512));
     return (int)std::min<long long>(std::max<long long>(M / 16, 1), cap);
 }
@@ -989,11 +993,14 @@ static int colsum_t(const void* x, long long M, int N, int ld, float* out, float
     constexpr int E = Chunk<T>::N;
     const int gy = colsum_gy(M, N);
     HS_REQUIRE(ws && ws_bytes >= (long long)gy * N * 4, "colsum: workspace too small");
+    const bool direct = gy == 1 && !accumulate;        // one row group: its sums go straight to `out`, no second launch
+    if (direct) ws = out;
     if (N % E == 0 && ld % E == 0 && ((((uintptr_t)x) & 15) == 0))
         hipLaunchKernelGGL(colsum_partial_vec_kernel<T>, dim3(ceil_div(N / E, 64), gy), dim3(256), 0, s, (const T*)x, M, N, ld, ws);
     else
         hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3(ceil_div(N, 256), gy), dim3(256), 0, s, (const T*)x, M, N, ld, ws);
     HS_LAUNCH_CHECK();
+    if (direct) return HS_OK;
     hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, s, ws, gy, N, out, accumulate);
     HS_LAUNCH_CHECK();
     return HS_OK;
@@ -1302,7 +1309,8 @@ hs_status hs_transpose_bf16_multi(int32_t count, const void* const* src, void* c
 hs_status hs_cross_entropy(const float* logits, const int64_t* labels, const float* weight, float label_smoothing,
                            int32_t B, int32_t C, float* loss, float* dlogits, float* row_loss, void* stream) {
     HS_REQUIRE(logits && labels && loss && B > 0 && C > 0, "cross_entropy: bad argument");
-    hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, (const long long*)labels, weight,
+    const int waves = B >= 32 ? 16 : B >= 16 ? 8 : 4;
+    hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(64 * waves), 0, (hipStream_t)stream, logits, (const long long*)labels, weight,
                        label_smoothing, B, C, loss, dlogits, row_loss);
     HS_LAUNCH_CHECK();
     return HS_OK;
