@@ -27,6 +27,7 @@ int gemm_stat_rows(const hs_gemm_params* p);
 int gemm_bn_finish_rows(const hs_gemm_params* p);
 int gemm_tile_rows(const hs_gemm_params* p);
 int gemm_bnb_finish_rows(const hs_gemm_params* p);
+void gemm_group_set_immediate_hook(int (*fn)(void*), void* ctx);
 struct GemmGroup;
 GemmGroup* gemm_group_open(hipStream_t s, long long slot);   // slot: any key that is stable across steps (its device table is cached)
 int gemm_group_add(GemmGroup* g, const hs_gemm_params* p, hipStream_t s);
@@ -76,6 +77,10 @@ struct Run {
     // BERT tower backward: the group above belongs to the TOWER and spans several layers (bert_bwd_run opens and flushes it);
     // a layer then neither opens nor flushes, and the tower keeps the layers' transposed operands allocated until the flush
     GemmGroup* tower_grp = nullptr;
+    // ... and the dY^T transposes those GEMMs read: collected here and made by ONE launch in front of the grouped grid (the
+    // row-major gradients stay allocated until then) instead of one launch each where the gradient appears
+    struct PendTr { const void* src; void* dst; int R, C; long long ld; };
+    std::vector<PendTr> pend_tr;
 };
 
 // one non-blocking side stream and a ring of events per device (events are re-recordable; every composite joins
@@ -553,8 +558,31 @@ static bool dgrad_nt_enabled() {          // HAMSPINE_DGRAD_NT=0: BERT data grad
     }
     return v == 1;
 }
-static int transpose_run(Run& r, const void* src, void* dst, long long R, int Cc, int ld_src) {
+static bool deferred_transposes_enabled() {     // HAMSPINE_DEFER_TRANSPOSES=0: one launch per dY^T where the gradient appears
+    static const bool on = [] { const char* e = getenv("HAMSPINE_DEFER_TRANSPOSES"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static int transpose_run(Run& r, const void* src, void* dst, long long R, int Cc, int ld_src, bool for_grouped_wgrad = false) {
+    if (for_grouped_wgrad && r.tower_grp && r.group_nt && !r.plan && deferred_transposes_enabled()) {       // its reader is the tower's grouped grid: see pend_tr
+        r.pend_tr.push_back(Run::PendTr{src, dst, (int)R, Cc, ld_src});
+        return HS_OK;
+    }
     CALLK(r, 4, hs_transpose_bf16(src, dst, (int)R, Cc, ld_src, R, r.s));
+    return HS_OK;
+}
+static int pending_transposes_flush(Run& r) {
+    const int n = (int)r.pend_tr.size();
+    if (n == 0) return HS_OK;
+    std::vector<const void*> src(n);
+    std::vector<void*> dst(n);
+    std::vector<int32_t> R(n), Cc(n);
+    std::vector<int64_t> lds(n), ldd(n);
+    for (int i = 0; i < n; ++i) {
+        src[i] = r.pend_tr[i].src; dst[i] = r.pend_tr[i].dst; R[i] = r.pend_tr[i].R; Cc[i] = r.pend_tr[i].C;
+        lds[i] = r.pend_tr[i].ld; ldd[i] = r.pend_tr[i].R;
+    }
+    r.pend_tr.clear();
+    CALLK(r, 4, hs_transpose_bf16_multi(n, src.data(), dst.data(), R.data(), Cc.data(), lds.data(), ldd.data(), r.s));
     return HS_OK;
 }
 // seg: 0 = plain; 3 = fused Q/K/V (lin = the q layer; D_seg / rowsum_seg = k, v)
@@ -1453,7 +1481,7 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
             r.group_nt = keep;
             return st;
         }
-        HS_PROPAGATE(transpose_run(r, dy_rm, tAk, M, lin.out_f, ldy));
+        HS_PROPAGATE(transpose_run(r, dy_rm, tAk, M, lin.out_f, ldy, true));
         const bool fused_b = lin.db && (r.group_nt || hs_gemm_suggest_split(lin.out_f, in_f, (int)M, r.dt) <= 1) && fused_bias_grad_enabled();
         HS_PROPAGATE(linear_wgrad_nt_run(r, xT, tAk, M, in_f, lin.out_f, lin.dw, lin.db, 0, nullptr, nullptr));
         if (lin.db && !fused_b) HS_PROPAGATE(bias_by_colsum(lin, dy_rm, ldy));
@@ -1518,7 +1546,7 @@ static int bert_layer_bwd_run(Run& r, const hs_bert_layer_desc& d, const void* x
         // one GEMM for the three weight gradients: [dWq; dWk; dWv] = dqkv^T x, rows routed to the three tensors
         const bool fused = d.q.dw && d.k.dw && d.v.dw;
         if (fused && nt) {
-            HS_PROPAGATE(transpose_run(r, dqkv, tA_qkv, M, 3 * Hd, 3 * Hd));
+            HS_PROPAGATE(transpose_run(r, dqkv, tA_qkv, M, 3 * Hd, 3 * Hd, true));
             const bool bias_too = d.q.db && d.k.db && d.v.db && (r.group_nt || hs_gemm_suggest_split(3 * Hd, Hd, (int)M, r.dt) <= 1) &&
                                   fused_bias_grad_enabled();
             float* dws[2] = {d.k.dw, d.v.dw};
@@ -1836,6 +1864,10 @@ static int bert_bwd_run(Run& r, const hs_bert_desc& d, const int64_t* ids, const
     int pending = 0;
     long long wm = 0;
     const void* gps[8][16];
+    struct HookGuard {          // a weight-gradient GEMM that gemm_group_add launches on its own must find its dY^T made
+        explicit HookGuard(Run* rr) { gemm_group_set_immediate_hook([](void* c) -> int { return pending_transposes_flush(*(Run*)c); }, rr); }
+        ~HookGuard() { gemm_group_set_immediate_hook(nullptr, nullptr); }
+    } hook_guard(&r);
     for (int i = d.n_layers - 1; i >= 0; --i) {
         const hs_bert_layer_desc l = bert_layer_of(d, i, mask);
         char* dx = gbuf[cur];
@@ -1852,6 +1884,7 @@ static int bert_bwd_run(Run& r, const hs_bert_desc& d, const int64_t* ids, const
         }
         ++pending;
         if (pending == span || i == 0) {
+            HS_PROPAGATE(pending_transposes_flush(r));
             if (r.tower_grp) HS_PROPAGATE(gemm_group_flush(r.tower_grp, r.s));
             r.tower_grp = nullptr;
             r.ws.release(wm);

@@ -702,9 +702,21 @@ int gemm_group_flush(GemmGroup* g, hipStream_t s) {
     g->flops = g->bytes = 0;
     return st;
 }
+// A caller that defers work a grouped GEMM depends on (the BERT tower's dY^T transposes) registers a hook: it runs before any
+// problem that gemm_group_add launches on its own instead of queueing.
+static thread_local int (*g_group_immediate_hook)(void*) = nullptr;
+static thread_local void* g_group_immediate_ctx = nullptr;
+void gemm_group_set_immediate_hook(int (*fn)(void*), void* ctx) {
+    g_group_immediate_hook = fn;
+    g_group_immediate_ctx = ctx;
+}
+static int launch_ungrouped(const hs_gemm_params* p, hipStream_t s) {
+    if (g_group_immediate_hook) HS_PROPAGATE(g_group_immediate_hook(g_group_immediate_ctx));
+    return gemm_impl(p, s);
+}
 // adds p to the group, or launches it on its own when it cannot be grouped (f32, another layout or tile, no in-launch reduce)
 int gemm_group_add(GemmGroup* g, const hs_gemm_params* p, hipStream_t s) {
-    if (!g) return gemm_impl(p, s);
+    if (!g) return launch_ungrouped(p, s);
     Prepared q;
     const bool big = p->a_kind == HS_A_KC && p->b_kind == HS_B_KC;       // K-contiguous weight gradients: 256x128 tiles
     // ... or, when every tile is a full 256 x 256 one and the group is a deep-K one (K >= 2048: the K walk has to amortise the
@@ -719,12 +731,14 @@ int gemm_group_add(GemmGroup* g, const hs_gemm_params* p, hipStream_t s) {
     const bool ok = big ? (q.bf16 && (q.cfg == CFG_256x128 || q.cfg == CFG_P8_256) && q.combo == 0 && q.batch == 1 && q.split == 1 && !q.a.stamps && !q.a.colstats)
                         : (q.bf16 && q.cfg == CFG_64x64 && (q.combo == 2 || q.combo == 5) && q.batch == 1 && !q.a.stamps &&
                            (q.split == 1 || q.a.tickets != nullptr) && !q.a.rowsum[0] && !q.a.colstats);
-    if (!ok) return gemm_impl(p, s);
+    if (!ok) return launch_ungrouped(p, s);
     const long long ngroups = q.split > 1 ? (q.split + kSplitGroup - 1) / kSplitGroup : 0;
     const long long need = q.split > 1 ? (long long)q.a.tiles_m * q.a.tiles_n * (1 + (ngroups > 1 ? ngroups : 0)) : 0;
-    if (!g->items.empty() && (g->combo != q.combo || (big && g->cfg != q.cfg) || (int)g->items.size() >= kGroupMax || g->ticket_off + need > kTicketPool))
+    if (!g->items.empty() && (g->combo != q.combo || (big && g->cfg != q.cfg) || (int)g->items.size() >= kGroupMax || g->ticket_off + need > kTicketPool)) {
+        if (g_group_immediate_hook) HS_PROPAGATE(g_group_immediate_hook(g_group_immediate_ctx));
         HS_PROPAGATE(gemm_group_flush(g, s));
-    if (need > kTicketPool) return gemm_impl(p, s);
+    }
+    if (need > kTicketPool) return launch_ungrouped(p, s);
     g->combo = q.combo;
     if (big) {
         g->cfg = q.cfg;
