@@ -60,7 +60,9 @@ def test_module_matches_reference_vectors(name):
     params = dict(m.named_parameters())
     for k, g in fx["gw"].items():
         assert params[k].grad is not None, f"{name}: no grad for {k}"
-        _close(params[k].grad, g, f"{name}: grad {k}", 5e-4, 1e-6)
+        # (atol: analytically zero gradients -- a self-attention's key bias -- are f32 rounding noise of ~1e-7 per term on both
+        # sides, and the order of the additions is the kernel's business)
+        _close(params[k].grad, g, f"{name}: grad {k}", 5e-4, 2e-6)
 
 
 # ------------------------------------------------------------------------------------------------------
