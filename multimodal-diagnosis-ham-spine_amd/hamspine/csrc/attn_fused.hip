@@ -47,14 +47,17 @@ struct AttnFusedArgs {
 // HD: head dimension (64: BERT; 32: the fusion modules' nn.MultiheadAttention(256, 8), reference modules/fusion_blocks.py:18-40,
 // 107-113).  blockIdx.y = query chunk: rows [128 y, 128 y + 128) of the Lq queries (the 784 x 128 score tile of the layer-2
 // CrossAttentionBlock is 7 chunks); every chunk stages all Lk <= 128 keys.
-template <int HD>
+// LK: key capacity of the workgroup (128, or 256: BERT at the MIBF loader's caption padding of 256 tokens -- 80 KiB of LDS, the
+// 128 x 256 score tile is 128 accumulator registers per lane)
+template <int HD, int LK = 128>
 __global__ __launch_bounds__(256) void attn_fwd_fused_kernel(const AttnFusedArgs a) {
-    constexpr int LMAX = 128, CPR = HD / 8, NP = LMAX * HD * 2 / 1024 / 4;      // DMA pieces per wave per tile
+    constexpr int LMAX = 128, CPR = HD / 8, NP = LMAX * HD * 2 / 1024 / 4;      // DMA pieces per wave per tile (queries)
+    constexpr int NPK = LK * HD * 2 / 1024 / 4;                                 // ... of the key / value tiles
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) char lds_char;
     char* Qs = smem;                    // [128 queries][64]  k-contiguous, XOR swizzled (kc_off_bf16<64>)
     char* Ks = smem + LMAX * HD * 2;    // [128 keys][64]     k-contiguous
-    char* Vs = smem + 2 * LMAX * HD * 2;  // [128 keys][64]   key-major ("row-contiguous") for the P V product
+    char* Vs = smem + (LMAX + LK) * HD * 2;  // [LK keys][64]   key-major ("row-contiguous") for the P V product
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,27 +74,33 @@ __global__ __launch_bounds__(256) void attn_fwd_fused_kernel(const AttnFusedArgs
     // ---- stage Q, K, V: LMAX * HD * 2 / 1024 LDS-DMA pieces (1 KiB) per tile, NP per wave ------------------------
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int s = (wave * NP + i) * 64 + lane;          // 16-byte slot of the tile
-        {   // K-contiguous tiles: row = s / CPR, physical chunk = s % CPR holds logical chunk pc ^ kc_swz(row)
+        const int s = (wave * NP + i) * 64 + lane;          // 16-byte slot of the query tile
+        const int r = s / CPR, pc = s % CPR;
+        const int kl = (pc ^ kc_swz<CPR>(r)) * 8;
+        const unsigned offq = q0 + r < a.Lq ? (unsigned)(((q0 + r) * a.q_ld + kl) * 2) : kOOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)((lds_char*)Qs + (wave * NP + i) * 1024), 16, offq, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NPK; ++i) {
+        const int s = (wave * NPK + i) * 64 + lane;         // 16-byte slot of the key / value tiles
+        {   // K-contiguous tile: row = s / CPR, physical chunk = s % CPR holds logical chunk pc ^ kc_swz(row)
             const int r = s / CPR, pc = s % CPR;
             const int kl = (pc ^ kc_swz<CPR>(r)) * 8;
-            const unsigned offq = q0 + r < a.Lq ? (unsigned)(((q0 + r) * a.q_ld + kl) * 2) : kOOB;
             const unsigned offk = r < a.Lk ? (unsigned)((r * a.k_ld + kl) * 2) : kOOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)((lds_char*)Qs + (wave * NP + i) * 1024), 16, offq, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)((lds_char*)Ks + (wave * NP + i) * 1024), 16, offk, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)((lds_char*)Ks + (wave * NPK + i) * 1024), 16, offk, 0, 0, 0);
         }
         {   // key-major V tile [key][HD]: key = s / CPR, physical chunk s % CPR holds logical chunk rc_logical_chunk
             const int key = s / (HD / 8), pcc = s % (HD / 8);
             const int col = rc_logical_chunk<HD>(key, pcc) * 8;
             const unsigned offv = key < a.Lk ? (unsigned)((key * a.v_ld + col) * 2) : kOOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)((lds_char*)Vs + (wave * NP + i) * 1024), 16, offv, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)((lds_char*)Vs + (wave * NPK + i) * 1024), 16, offv, 0, 0, 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // ---- S = Q K^T: this wave owns query rows [32 wave, 32 wave + 32) ---------------------------------------------
-    constexpr int FM = 2, FN = 8;
+    constexpr int FM = 2, FN = LK / 16;
     f32x4 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(256) void attn_fwd_fused_kernel(const AttnFusedArgs
 #pragma unroll
         for (int jn = 0; jn < FO; ++jn) oacc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kk = 0; kk < LMAX / 32; ++kk) {
+    for (int kk = 0; kk < LK / 32; ++kk) {
         bf16x8 pa[FM], vb[FO];
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
@@ -699,8 +708,9 @@ int attention_fwd_fused(const hs_attn_desc& d, const void* q, const void* k, con
         enabled = (e && e[0] == '0') ? 0 : 1;
     }
     // head dim 64 (BERT) or 32 (the fusion modules' 8-head attention over 256 features), any number of queries (128-row
-    // chunks on grid.y), at most 128 keys (every attention of the path except a BERT run at L > 128)
-    if (!enabled || d.dtype != HS_BF16 || (d.hd != 64 && d.hd != 32) || d.Lq < 1 || d.Lq > 128 * 65535 || d.Lk < 1 || d.Lk > 128 || ldP % 4 != 0 || ldP < d.Lk) return 0;
+    // chunks on grid.y), at most 128 keys -- 256 at head dim 64, forward only: the backward of such a call takes the unfused
+    // kernels on the probabilities this kernel stored
+    if (!enabled || d.dtype != HS_BF16 || (d.hd != 64 && d.hd != 32) || d.Lq < 1 || d.Lq > 128 * 65535 || d.Lk < 1 || d.Lk > (d.hd == 64 ? 256 : 128) || ldP % 4 != 0 || ldP < d.Lk) return 0;
     const long long strides[] = {d.q_bs, d.k_bs, d.v_bs, d.o_bs, d.q_ld, d.k_ld, d.v_ld, d.o_ld};
     for (long long x : strides)
         if (x % 8 != 0) return 0;
@@ -730,10 +740,12 @@ int attention_fwd_fused(const hs_attn_desc& d, const void* q, const void* k, con
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)attn_fwd_fused_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 64 * 2) != hipSuccess) return -1;
         if (hipFuncSetAttribute((const void*)attn_fwd_fused_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 32 * 2) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)attn_fwd_fused_kernel<64, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (128 + 2 * 256) * 64 * 2) != hipSuccess) return -1;
         attr_set = true;
     }
     const dim3 grid(d.B * d.H, (d.Lq + 127) / 128);
-    if (d.hd == 64) hipLaunchKernelGGL(attn_fwd_fused_kernel<64>, grid, dim3(256), 3 * 128 * 64 * 2, s, a);
+    if (d.hd == 64 && d.Lk > 128) hipLaunchKernelGGL((attn_fwd_fused_kernel<64, 256>), grid, dim3(256), (128 + 2 * 256) * 64 * 2, s, a);
+    else if (d.hd == 64) hipLaunchKernelGGL(attn_fwd_fused_kernel<64>, grid, dim3(256), 3 * 128 * 64 * 2, s, a);
     else hipLaunchKernelGGL(attn_fwd_fused_kernel<32>, grid, dim3(256), 3 * 128 * 32 * 2, s, a);
     if (hipGetLastError() != hipSuccess) return -1;
     return 1;

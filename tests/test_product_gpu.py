@@ -781,10 +781,14 @@ def test_fused_attention_bert_shape_matches_reference(L, masked):
     (8, 32, 196, 128, False),    # layer-3 CrossAttentionBlock: 2 chunks, the second one ragged
     (4, 64, 300, 128, True),     # head dim 64 beyond 128 queries: the chunk-walking backward (dK / dV summed over chunks)
     (4, 64, 129, 64, False),     # one row into the second chunk, fewer keys than a tile
+    (12, 64, 256, 256, True),    # BERT at the MIBF loader's caption padding: 256 keys (forward fused, backward on the stored P)
+    (4, 64, 130, 200, True),     # ragged in both directions
+    (2, 64, 64, 256, False),
 ])
 def test_fused_attention_general_shapes_match_reference(H, hd, Lq, Lk, masked):
     """The generalised fused kernels (csrc/attn_fused.hip: head dim 32 / 64, any number of queries in 128-row chunks,
-    <= 128 keys) against f32 torch attention on the same bf16-rounded q, k, v: output and dq, dk, dv."""
+    <= 128 keys; <= 256 keys at head dim 64 in the forward) against f32 torch attention on the same bf16-rounded q, k, v:
+    output and dq, dk, dv."""
     from hamspine import convnext_ops as X
     hamspine.set_compute_dtype("bf16")
     B = 3
@@ -826,14 +830,14 @@ def test_fused_attention_general_shapes_match_reference(H, hd, Lq, Lk, masked):
     assert sum(cnt) == 0, "this shape should not launch score / context GEMMs: the fused kernel covers it"
 
 
-@pytest.mark.parametrize("hd", [64, 32])
-def test_attention_dropout_mask_is_the_same_in_forward_and_backward(hd):
+@pytest.mark.parametrize("hd,L", [(64, 128), (32, 128), (64, 256)])
+def test_attention_dropout_mask_is_the_same_in_forward_and_backward(hd, L):
     """With V = 1 the output is the row sum of the dropped-out probabilities Pd, and with dO = 1 the gradient dV is its
     column sum: both total sum(Pd), so forward and backward must have regenerated the same mask (fused kernels at both
-    head dims).  The kept fraction is checked against 1 - p."""
+    head dims; 256 keys: fused forward, unfused backward).  The kept fraction is checked against 1 - p."""
     from hamspine import convnext_ops as X
     hamspine.set_compute_dtype("bf16")
-    B, H, L, p = 4, 4, 128, 0.25
+    B, H, p = 4, 4, 0.25
     g = torch.Generator().manual_seed(hd)
     q, k = (torch.randn(B, L, H * hd, generator=g).bfloat16().to(DEV) for _ in range(2))
     v = torch.ones(B, L, H * hd, dtype=torch.bfloat16, device=DEV).requires_grad_(True)
